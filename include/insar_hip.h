@@ -1,0 +1,243 @@
+/*
+ * insar_hip.h — flat C ABI of libinsar_hip.so (gfx950 / MI355X).
+ *
+ * The reference (Createroner/InSAR-Unet-CA) has no FFI layer: its boundary is the
+ * torch nn.Module API of Unet-ChannalAttention.py. This header is the thin C ABI the
+ * Python host (insar_unet_ca_amd/) binds with ctypes; every entry point names the
+ * reference arithmetic it replaces (file:line into /root/reference).
+ *
+ * Conventions
+ *  - Every function returns 0 on success, a negative INSAR_E_* code or -hipError_t on
+ *    failure; insar_last_error() returns a thread-local message. No C++ exception
+ *    crosses the ABI.
+ *  - The library never allocates, frees or synchronises: every buffer is caller-owned
+ *    device memory (torch tensors passed as raw pointers); kernels are enqueued on the
+ *    caller's hipStream_t (passed as void*) and the call returns immediately.
+ *  - Activations are NHWC with a one-pixel zero halo: [B][H+2][W+2][C] elements of
+ *    `dtype` (INSAR_F32 / INSAR_BF16). Kernels write interiors only, so the halo of a
+ *    buffer allocated zeroed stays zero (that is what pads the 3x3 convolutions).
+ *    An InsarAct describes a channel slice [c_off, c_off+c_len) of such a buffer, which
+ *    is how the skip-concat (Unet-ChannalAttention.py:140,146,152,158) is zero-copy.
+ */
+#ifndef INSAR_HIP_H
+#define INSAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INSAR_ABI_VERSION 1
+
+enum { INSAR_F32 = 0, INSAR_BF16 = 1 };
+
+enum {
+  INSAR_OK = 0,
+  INSAR_E_SHAPE = -1001, /* unsupported / inconsistent shape */
+  INSAR_E_DTYPE = -1002,
+  INSAR_E_ALIGN = -1003, /* pointer not 16-byte aligned */
+  INSAR_E_WS = -1004,    /* workspace too small */
+  INSAR_E_ARG = -1005
+};
+
+typedef struct InsarAct {
+  void* ptr;     /* base of the padded buffer (pixel (-1,-1) of image 0, channel 0) */
+  int32_t B, H, W; /* interior extent */
+  int32_t C;     /* channels of the whole buffer (pixel pitch, elements) */
+  int32_t c_off; /* first channel of the slice */
+  int32_t c_len; /* channels in the slice */
+  int32_t dtype; /* INSAR_F32 | INSAR_BF16 */
+  int32_t _pad;
+} InsarAct;
+
+int insar_version(void);
+const char* insar_last_error(void);
+
+/* ---- layout conversion at the nn.Module boundary (forward(x:[B,C,H,W]), :127) ------------ */
+/* NCHW contiguous fp32 -> padded NHWC slice (cast to dst.dtype). */
+int insar_pack_nchw(const float* src, const InsarAct* dst, void* stream);
+/* padded NHWC slice -> NCHW contiguous fp32. */
+int insar_unpack_nchw(const InsarAct* src, float* dst, void* stream);
+
+/* ---- weight re-layout: torch fp32 parameter -> GEMM operand [t][n][k] of `dtype` ----------
+ * out[(t*N + n)*K + k] = cast(in[t*st + n*sn + k*sk]).  Used for Conv2d (Co,Ci,3,3) weights
+ * (:81,84), ConvTranspose2d (Ci,Co,2,2) weights (:112-121) in their forward and dgrad forms. */
+int insar_weight_prep(const float* in, void* out, int32_t dtype, int32_t T, int32_t N, int32_t K,
+                      int64_t st, int64_t sn, int64_t sk, void* stream);
+
+/* ---- implicit-GEMM convolution family (MFMA) ------------------------------------------------
+ * y[pix(m), n] = sum_{tap, k} x[in_pix(m, tap), k] * w[tap][n][k]  (+ bias[n])
+ *   m enumerates the out.B x Ho x Wo grid row-major; in_pix = (ho*stride + dy[tap], wo*stride + dx[tap]).
+ * mode 0: Conv2d 3x3 pad 1 forward (:81,84) / its dgrad (flipped taps, transposed weights) /
+ *         ConvTranspose2d dgrad (stride 2, taps {0,1}^2): out pixel (ho,wo), channel n.
+ * mode 1: ConvTranspose2d(k=2,s=2) forward (:112,115,118,121): N = 4*Cout, n=(a*2+b)*Cout+co
+ *         is scattered to out pixel (2ho+a, 2wo+b), channel co.
+ * stats (nullable): per-M-tile partial column sums of the stored output,
+ *         float[insar_igemm_num_mtiles(M)][2][N] (sum, sum of squares) for BatchNorm (:82,85). */
+typedef struct InsarIgemm {
+  InsarAct x;          /* input slice, c_len = K per tap */
+  InsarAct y;          /* output slice */
+  const void* w;       /* [ntaps][N][K] of x.dtype */
+  const float* bias;   /* nullable, per output channel */
+  float* stats;        /* nullable */
+  int32_t N;           /* GEMM N (mode 1: 4*Cout) */
+  int32_t Ho, Wo;      /* GEMM row grid (per image) */
+  int32_t stride;      /* 1 or 2 */
+  int32_t ntaps;       /* 1, 4 or 9 */
+  int32_t mode;        /* 0 | 1 */
+  int8_t dy[12], dx[12];
+} InsarIgemm;
+int insar_igemm_num_mtiles(int64_t M);
+int insar_igemm(const InsarIgemm* d, void* stream);
+
+/* ---- weight-gradient GEMM (MFMA, split-K over pixels, no atomics) ------------------------------
+ * part[split][tap][co][ci] = sum_{p in split} dy[pixB(p,tap), co] * x[pixA(p,tap), ci]
+ * with pixA/pixB given as int32 pixel-index tables (padded-buffer pixel index of tap (0,0) for
+ * every flattened p, length Mpad = multiple of 64, tail entries 0 = a halo pixel) plus a per-tap
+ * pixel offset. Covers Conv2d wgrad (x taps move) and ConvTranspose2d wgrad (dy taps move). */
+typedef struct InsarWgrad {
+  InsarAct x;             /* c_len = Cin */
+  InsarAct dy;            /* c_len = Cout */
+  const int32_t* tabx;    /* [Mpad] */
+  const int32_t* tabdy;   /* [Mpad] */
+  float* part;            /* [nsplit][ntaps][Cout][Cin] fp32 */
+  int64_t Mpad;           /* padded pixel count (multiple of 64) */
+  int32_t nsplit;
+  int32_t ntaps;
+  int32_t offx[12];       /* per-tap pixel offset added to tabx entries */
+  int32_t offdy[12];      /* per-tap pixel offset added to tabdy entries */
+} InsarWgrad;
+int insar_wgrad(const InsarWgrad* d, void* stream);
+/* grad = sum_split part[...] re-laid out to the torch parameter layout.
+ * layout 0: Conv2d (Co,Ci,kh,kw): grad[(co*Ci+ci)*ntaps + tap]
+ * layout 1: ConvTranspose2d (Ci,Co,2,2): grad[(ci*Co+co)*ntaps + tap]
+ * accumulate != 0 adds into grad instead of overwriting. */
+int insar_wgrad_reduce(const float* part, float* grad, int32_t nsplit, int32_t ntaps, int32_t Co,
+                       int32_t Ci, int32_t layout, int32_t accumulate, void* stream);
+/* pixel-index table for a B x H x W grid mapped with stride s into a padded buffer of interior
+ * (Hb, Wb): tab[p] = (n*(Hb+2) + h*s + 1)*(Wb+2) + w*s + 1 ; entries p >= B*H*W are `tail`
+ * (0 = a zero halo pixel for the operand whose taps do not move; Wb+3 = the first interior pixel,
+ * in bounds under every 3x3 tap, for the operand whose taps move). */
+int insar_pixel_table(int32_t* tab, int64_t Mpad, int32_t B, int32_t H, int32_t W, int32_t s,
+                      int32_t Hb, int32_t Wb, int32_t tail, void* stream);
+
+/* ---- first layer: direct 3x3 conv for tiny Cin (inc.double_conv.0, Cin<=4; :81 with :464) ---- */
+int insar_conv3x3_small_fwd(const InsarAct* x, const float* w /*torch (Co,Ci,3,3) fp32*/,
+                            const InsarAct* y, float* stats /*[B*H][2][Co]*/, void* stream);
+/* part: [insar_conv3x3_small_wgrad_blocks(B,H)][Co*Ci*9] partial rows (torch (Co,Ci,3,3) order). */
+int insar_conv3x3_small_wgrad_blocks(int32_t B, int32_t H);
+int insar_conv3x3_small_wgrad(const InsarAct* x, const InsarAct* dy, float* part, void* stream);
+
+/* ---- segmented column sum of partial slabs: out[s][c] (+)= sum_r part[s][r][c] ---------------
+ * Two-stage (deterministic, no atomics) when rows > 256: stage 1 writes into `tmp`
+ * (>= ceil(rows/128)*segments*cols floats), stage 2 folds it. */
+int insar_colsum(const float* part, float* out, int32_t segments, int64_t rows, int32_t cols,
+                 int32_t accumulate, float* tmp, int64_t tmp_floats, void* stream);
+
+/* ---- BatchNorm2d (+ReLU) (:82-83, :85-86) -------------------------------------------------------
+ * finalize: from the column sums part[2][C] (sum, sum of squares; insar_colsum of the stats slabs) of
+ * the raw (bias-free) conv output over `count` pixels: batch mean/var -> scale = gamma*invstd, shift = beta - mean*scale; running stats
+ * (momentum, unbiased var; the conv bias is added to the mean) and num_batches_tracked.
+ * training == 0: scale/shift from the running stats (+ conv bias), slabs ignored. */
+typedef struct InsarBnFinalize {
+  const float* part; int64_t count; int32_t C; int32_t training;
+  const float* conv_bias; const float* gamma; const float* beta;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float momentum; float eps;
+  float* scale; float* shift; float* mean; float* invstd; /* outputs, [C] each */
+} InsarBnFinalize;
+int insar_bn_finalize(const InsarBnFinalize* d, void* stream);
+/* z = relu(y*scale + shift) * gate[n][c] (gate nullable) -> dst slice. `relu` = 0 drops the ReLU
+ * (and the mask in the reductions below): that is the stand-alone SELayer applied to a raw tensor. */
+int insar_bn_relu_apply(const InsarAct* y, const float* scale, const float* shift,
+                        const float* gate /*[B][C] or null*/, const InsarAct* dst, int32_t relu,
+                        void* stream);
+
+/* ---- SELayer (:45-72) ----------------------------------------------------------------------------
+ * squeeze: per (n, image row, c) partial sums over w of mask and mask*y, mask = (y*scale+shift > 0):
+ *   part[B*H][2][C]. */
+int insar_se_squeeze(const InsarAct* y, const float* scale, const float* shift, float* part,
+                     int32_t relu, void* stream);
+/* excitation: mean -> Linear(C,C/r) -> ReLU -> Linear(C/r,C) -> Sigmoid (two bias-free Linears,
+ * :54-59). Saves sq[B][C] (the squeezed mean), hid[B][Cr] (post-ReLU), gate[B][C]. */
+typedef struct InsarSeFwd {
+  const float* pooled; /* [B][2][C]: per image sum of mask, sum of mask*y (insar_colsum of the squeeze slabs) */
+  int32_t B, H, W, C, Cr; int32_t _pad;
+  const float* scale; const float* shift;
+  const float* w1; /* (Cr, C) */ const float* w2; /* (C, Cr) */
+  float* sq; float* hid; float* gate;
+} InsarSeFwd;
+int insar_se_excite(const InsarSeFwd* d, void* stream);
+
+/* ---- backward of [BN -> ReLU -> (SE gate)] ------------------------------------------------------
+ * reduce: part[B*H][2][C] = per (n,row) sums over w of  g*mask  and  g*mask*y , g = dout (T).  */
+int insar_bnrelu_bwd_reduce(const InsarAct* dout, const InsarAct* y, const float* scale,
+                            const float* shift, float* part, int32_t relu, void* stream);
+/* coefficient kernels: turn the per-image reduced sums red[B][2][C] (insar_colsum of the reduce
+ * slabs) into everything the apply pass needs.
+ *  with SE:  ds -> MLP backward (dW1, dW2, dsq);  g_eff = (dout*gate + dsq/HW) on the ReLU mask
+ *  dgamma/dbeta; coefB[B][C] = dsq/HW and per-channel k1[C] = dbeta/N, k2[C] = dgamma/N (0 in eval):
+ *    dy = scale_c * ( (dout*gate + coefB)*mask - k1 - xhat*k2 ).
+ *  dconv_bias (nullable): gradient of the bias of the conv feeding this BN: exactly 0 in training
+ *  (the batch mean removes it), scale*dbeta in eval.
+ *  ws: float[B*(3C + Cr)] scratch. */
+typedef struct InsarBnSeBwd {
+  int32_t B, H, W, C, Cr; int32_t use_se;
+  const float* mean; const float* invstd;
+  const float* pooled; const float* sq; const float* hid; const float* gate;
+  const float* w1; const float* w2;
+  float* dw1; float* dw2; float* dgamma; float* dbeta;
+  float* coefB; float* k1; float* k2;
+  int32_t accumulate; int32_t _pad;
+} InsarBnSeBwd;
+int insar_bnse_bwd_coef(const InsarBnSeBwd* d, const float* red, const float* scale, const float* shift,
+                        float* ws, float* dconv_bias, int32_t training, void* stream);
+int insar_bnrelu_bwd_apply(const InsarAct* dout, const InsarAct* y, const float* scale,
+                           const float* shift, const float* mean, const float* invstd,
+                           const float* gate, const float* coefB, const float* k1,
+                           const float* k2, const InsarAct* dy, int32_t relu, void* stream);
+
+/* ---- MaxPool2d(2) (:106-109) -------------------------------------------------------------------- */
+int insar_maxpool2_fwd(const InsarAct* x, const InsarAct* y, void* stream);
+/* dx (+)= route(dy) to the first maximum in scan order (torch semantics). */
+int insar_maxpool2_bwd(const InsarAct* x, const InsarAct* dy, const InsarAct* dx, int32_t accumulate,
+                       void* stream);
+
+/* ---- outc: Conv2d(64, num_classes, 1) (:125,162) ------------------------------------------------ */
+int insar_conv1x1_out_fwd(const InsarAct* x, const float* w /*(K,C)*/, const float* bias,
+                          float* logits /*NCHW fp32*/, int32_t K, void* stream);
+/* dx slice <- dlogits * W ; part[insar_conv1x1_out_bwd_blocks(B,H)][K*C + K] partial (dW, dbias) sums. */
+int insar_conv1x1_out_bwd_blocks(int32_t B, int32_t H);
+int insar_conv1x1_out_bwd(const InsarAct* x, const float* w, const float* dlogits, int32_t K,
+                          const InsarAct* dx, float* part, void* stream);
+
+/* ---- loss entry: CrossEntropyLoss(ignore_index) (:465,344), fused forward + gradient ----------- */
+/* ws: float[2 + 2*blocks] scratch (blocks = insar_ce_blocks(npix)); loss_out[0] = mean loss,
+ * dlogits = (softmax - onehot)/n_valid on valid pixels, 0 elsewhere. */
+int insar_ce_blocks(int64_t npix);
+int insar_cross_entropy(const float* logits, const int64_t* target, int32_t B, int32_t K, int64_t HW,
+                        int64_t ignore_index, float* dlogits, float* loss_out, float* ws, void* stream);
+/* soft-Dice on softmax probabilities (build-side addition; the reference has no Dice). */
+int insar_dice(const float* logits, const int64_t* target, int32_t B, int32_t K, int64_t HW,
+               int64_t ignore_index, float smooth, float* dlogits, float* loss_out, float* ws,
+               void* stream);
+
+/* ---- metrics (compute_metrics, :215-269): argmax (ties -> lower class) + TP/FP/FN counts -------- */
+int insar_confusion(const float* logits, const int64_t* target, int32_t B, int32_t K, int64_t HW,
+                    int64_t ignore_index, int64_t* counts /*[3][K], zeroed by the call*/, void* stream);
+
+/* ---- optimizer: optim.Adam(lr=1e-4) (:466,346), multi-tensor ------------------------------------
+ * table: int64[ntensors][5] = {param*, grad*, exp_avg*, exp_avg_sq*, numel}; chunks: int32[nchunks][2]
+ * = {tensor index, chunk index}; each chunk covers `chunk_elems` elements. */
+int insar_adam_step(const int64_t* table, const int32_t* chunks, int32_t nchunks, int32_t chunk_elems,
+                    float lr, float beta1, float beta2, float eps, float bias_correction1,
+                    float bias_correction2_sqrt, float grad_scale, void* stream);
+
+/* ---- small helpers ---------------------------------------------------------------------------- */
+int insar_scale_f32(float* p, int64_t n, float s, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INSAR_HIP_H */

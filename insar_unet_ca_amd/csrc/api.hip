@@ -1,0 +1,31 @@
+// Error plumbing and argument validation shared by every entry point of libinsar_hip.so.
+#include <stdarg.h>
+#include <string.h>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void insar_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* insar_last_error(void) { return g_err; }
+extern "C" int insar_version(void) { return INSAR_ABI_VERSION; }
+
+int insar_check_act(const InsarAct* a, const char* who, const char* what) {
+  if (!a || !a->ptr) INSAR_FAIL(INSAR_E_ARG, "%s: %s is null", who, what);
+  if (a->dtype != INSAR_F32 && a->dtype != INSAR_BF16) INSAR_FAIL(INSAR_E_DTYPE, "%s: %s has dtype %d", who, what, a->dtype);
+  const int ch = a->dtype == INSAR_BF16 ? 8 : 4;
+  if (a->B < 1 || a->H < 1 || a->W < 1 || a->C < 1 || a->c_len < 1 || a->c_off < 0 || a->c_off + a->c_len > a->C)
+    INSAR_FAIL(INSAR_E_SHAPE, "%s: %s has a bad extent B=%d H=%d W=%d C=%d slice=[%d,+%d)", who, what, a->B, a->H, a->W,
+               a->C, a->c_off, a->c_len);
+  if ((a->C % ch) || (a->c_off % ch) || (a->c_len % ch))
+    INSAR_FAIL(INSAR_E_SHAPE, "%s: %s channel slice must be a multiple of %d elements (16 bytes)", who, what, ch);
+  if (!insar_aligned16(a->ptr)) INSAR_FAIL(INSAR_E_ALIGN, "%s: %s is not 16-byte aligned", who, what);
+  const long long bytes = (long long)a->B * (a->H + 2) * (a->W + 2) * a->C * (a->dtype == INSAR_BF16 ? 2 : 4);
+  if (bytes <= 0) INSAR_FAIL(INSAR_E_SHAPE, "%s: %s size overflow", who, what);
+  return INSAR_OK;
+}

@@ -1,0 +1,104 @@
+// Shared device/host helpers for libinsar_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "insar_hip.h"
+
+#define INSAR_WAVE 64
+
+// ---- error plumbing -----------------------------------------------------------------------
+void insar_set_error(const char* fmt, ...);
+#define INSAR_FAIL(code, ...)        \
+  do {                               \
+    insar_set_error(__VA_ARGS__);    \
+    return (code);                   \
+  } while (0)
+#define INSAR_CHECK_LAUNCH(name)                                         \
+  do {                                                                   \
+    hipError_t e__ = hipGetLastError();                                  \
+    if (e__ != hipSuccess) {                                             \
+      insar_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return -(int)e__;                                                  \
+    }                                                                    \
+  } while (0)
+
+static inline bool insar_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// ---- element types ------------------------------------------------------------------------
+struct bf16_t { uint16_t v; };
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> { static constexpr int kPerChunk = 4; static constexpr int kDtype = INSAR_F32; };
+template <> struct ElemTraits<bf16_t> { static constexpr int kPerChunk = 8; static constexpr int kDtype = INSAR_BF16; };
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+  return __builtin_bit_cast(uint16_t, h);
+}
+
+// 16-byte chunk <-> float lanes
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+  static constexpr int N = 4;
+  __device__ __forceinline__ static void unpack(const uint4& u, float* f) {
+    f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y); f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+  }
+  __device__ __forceinline__ static uint4 pack(const float* f) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+  }
+};
+template <> struct Chunk<bf16_t> {
+  static constexpr int N = 8;
+  __device__ __forceinline__ static void unpack(const uint4& u, float* f) {
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+  }
+  __device__ __forceinline__ static uint4 pack(const float* f) {
+    uint4 u;
+    u.x = (uint32_t)f32_to_bf16(f[0]) | ((uint32_t)f32_to_bf16(f[1]) << 16);
+    u.y = (uint32_t)f32_to_bf16(f[2]) | ((uint32_t)f32_to_bf16(f[3]) << 16);
+    u.z = (uint32_t)f32_to_bf16(f[4]) | ((uint32_t)f32_to_bf16(f[5]) << 16);
+    u.w = (uint32_t)f32_to_bf16(f[6]) | ((uint32_t)f32_to_bf16(f[7]) << 16);
+    return u;
+  }
+};
+
+// ---- padded NHWC view ---------------------------------------------------------------------
+struct ActView {
+  char* base;      // byte pointer to element 0 of the padded buffer
+  int B, H, W, C, c_off, c_len;
+  int esize;       // bytes per element
+  __host__ __device__ __forceinline__ int64_t pixel_index(int n, int h, int w) const {
+    // interior pixel (h, w) of image n -> index of the padded pixel
+    return ((int64_t)n * (H + 2) + (h + 1)) * (W + 2) + (w + 1);
+  }
+  __host__ __device__ __forceinline__ int64_t elem_offset(int n, int h, int w) const {
+    return pixel_index(n, h, w) * C + c_off;
+  }
+};
+
+static inline ActView make_view(const InsarAct& a) {
+  ActView v;
+  v.base = (char*)a.ptr; v.B = a.B; v.H = a.H; v.W = a.W; v.C = a.C; v.c_off = a.c_off; v.c_len = a.c_len;
+  v.esize = (a.dtype == INSAR_BF16) ? 2 : 4;
+  return v;
+}
+
+// Validate an activation slice: aligned base, 16-byte-aligned channel slice.
+int insar_check_act(const InsarAct* a, const char* who, const char* what);
+
+// ---- wave helpers -------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int insar_grid_cap(int64_t want, int cap = 2048 * 4) {
+  if (want < 1) want = 1;
+  return (int)(want > cap ? cap : want);
+}

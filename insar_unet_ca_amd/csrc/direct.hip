@@ -1,0 +1,345 @@
+// Direct (VALU, HBM-bound) kernels for the two layers whose channel count is too small for the
+// matrix cores: the first 3x3 conv (Cin = in_channels <= 4, Unet-ChannalAttention.py:81 via :464)
+// and outc, the 1x1 conv to num_classes (:125,162), forward and backward.
+#include "common.h"
+
+#define DR_THREADS 256
+#define DR_MAXCI 4
+#define DR_MAXK 8
+
+template <typename T>
+__device__ __forceinline__ float load_elem(const char* p) {
+  if constexpr (sizeof(T) == 2) return bf16_to_f32(*(const uint16_t*)p);
+  else return *(const float*)p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// first-layer conv forward: thread -> (pixel w, 16-byte chunk of output channels)
+// stats: part[(n*H + h)][2][Co] partial sums of the stored output over the row.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void conv3x3_small_fwd_kernel(ActView x, const float* __restrict__ wt, ActView y, float* __restrict__ part) {
+  constexpr int CH = Chunk<T>::N;
+  extern __shared__ float sm[];
+  const int Ci = x.c_len, Co = y.c_len;
+  float* sw = sm;                                   // [9*Ci][Co]
+  float* red = sm + 9 * Ci * Co;                    // [DR_THREADS][2*CH+1]
+  for (int i = threadIdx.x; i < 9 * Ci * Co; i += blockDim.x) {
+    const int k = i / Co, co = i - k * Co;         // k = tap*Ci + ci
+    const int tap = k / Ci, ci = k - tap * Ci;
+    sw[i] = wt[((int64_t)co * Ci + ci) * 9 + tap];
+  }
+  __syncthreads();
+  const int cpp = Co / CH;
+  const int rows = y.B * y.H;
+  const int total = y.W * cpp;
+  const int cc = threadIdx.x % cpp;                 // host guarantees blockDim % cpp == 0
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int n = r / y.H, h = r - n * y.H;
+    float s1[CH], s2[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+      const int w = e / cpp;
+      float acc[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) acc[j] = 0.f;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const char* px = x.base + x.elem_offset(n, h + dy, w + dx) * (int64_t)sizeof(T);
+        for (int ci = 0; ci < Ci; ++ci) {
+          const float xv = load_elem<T>(px + ci * sizeof(T));
+          const float* wrow = sw + (tap * Ci + ci) * Co + cc * CH;
+#pragma unroll
+          for (int j = 0; j < CH; ++j) acc[j] = fmaf(xv, wrow[j], acc[j]);
+        }
+      }
+      const uint4 packed = Chunk<T>::pack(acc);
+      float f[CH];
+      Chunk<T>::unpack(packed, f);                  // statistics of the stored (rounded) values
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { s1[j] += f[j]; s2[j] = fmaf(f[j], f[j], s2[j]); }
+      *(uint4*)(y.base + (y.elem_offset(n, h, w) + (int64_t)cc * CH) * (int64_t)sizeof(T)) = packed;
+    }
+    if (part) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { red[threadIdx.x * (2 * CH + 1) + j] = s1[j]; red[threadIdx.x * (2 * CH + 1) + CH + j] = s2[j]; }
+      __syncthreads();
+      for (int o = threadIdx.x; o < 2 * Co; o += blockDim.x) {
+        const int q = o / Co, c = o - q * Co;
+        const int occ = c / CH, j = c - occ * CH;
+        float s = 0.f;
+        for (int t = occ; t < blockDim.x; t += cpp) s += red[t * (2 * CH + 1) + q * CH + j];
+        part[((int64_t)r * 2 + q) * Co + c] = s;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+static int check_small(const InsarAct* x, const InsarAct* y, const char* who) {
+  if (!x || !y || !x->ptr || !y->ptr) INSAR_FAIL(INSAR_E_ARG, "%s: null pointer", who);
+  if (x->dtype != y->dtype) INSAR_FAIL(INSAR_E_DTYPE, "%s: dtype differ", who);
+  if (x->B != y->B || x->H != y->H || x->W != y->W) INSAR_FAIL(INSAR_E_SHAPE, "%s: grid differs", who);
+  if (x->c_len < 1 || x->c_len > DR_MAXCI) INSAR_FAIL(INSAR_E_SHAPE, "%s: Cin=%d must be 1..%d", who, x->c_len, DR_MAXCI);
+  const int ch = y->dtype == INSAR_BF16 ? 8 : 4;
+  const int cpp = y->c_len / ch;
+  if (y->c_len % ch || cpp < 1 || cpp > 64 || (cpp & (cpp - 1)) || (DR_THREADS % cpp))
+    INSAR_FAIL(INSAR_E_SHAPE, "%s: Cout=%d unsupported", who, y->c_len);
+  return insar_check_act(y, who, "y");
+}
+
+extern "C" int insar_conv3x3_small_fwd(const InsarAct* x, const float* w, const InsarAct* y, float* stats, void* stream) {
+  int rc;
+  if ((rc = check_small(x, y, "insar_conv3x3_small_fwd"))) return rc;
+  if (!w) INSAR_FAIL(INSAR_E_ARG, "insar_conv3x3_small_fwd: null weights");
+  const int ch = y->dtype == INSAR_BF16 ? 8 : 4;
+  size_t lds = (size_t)(9 * x->c_len * y->c_len + DR_THREADS * (2 * ch + 1)) * sizeof(float);
+  int grid = insar_grid_cap((int64_t)y->B * y->H);
+  hipStream_t s = (hipStream_t)stream;
+  if (y->dtype == INSAR_BF16) hipLaunchKernelGGL(conv3x3_small_fwd_kernel<bf16_t>, dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), w, make_view(*y), stats);
+  else hipLaunchKernelGGL(conv3x3_small_fwd_kernel<float>, dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), w, make_view(*y), stats);
+  INSAR_CHECK_LAUNCH("insar_conv3x3_small_fwd");
+  return INSAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// first-layer conv weight gradient: dW[co][ci][tap] = sum_pix x[pix+tap, ci] * dy[pix, co]
+// Each block accumulates over its rows (grid-stride) in registers, reduces across the lanes that
+// own the same channel chunk (wave shuffles, then LDS across waves) and writes ONE partial row:
+// part[block][Co*Ci*9] in torch (Co,Ci,3,3) order. insar_colsum folds the blocks.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void conv3x3_small_wgrad_kernel(ActView x, ActView dy, float* __restrict__ part) {
+  constexpr int CH = Chunk<T>::N;
+  extern __shared__ float sm[];                     // [4 waves][cpp][9][CH]
+  const int Ci = x.c_len, Co = dy.c_len;
+  const int cpp = Co / CH;
+  const int rows = dy.B * dy.H;
+  const int total = dy.W * cpp;
+  const int cc = threadIdx.x % cpp;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int ci = 0; ci < Ci; ++ci) {
+    float acc[9][CH];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < CH; ++j) acc[t][j] = 0.f;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+      const int n = r / dy.H, h = r - n * dy.H;
+      for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int w = e / cpp;
+        float g[CH];
+        Chunk<T>::unpack(*(const uint4*)(dy.base + (dy.elem_offset(n, h, w) + (int64_t)cc * CH) * (int64_t)sizeof(T)), g);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const float xv = load_elem<T>(x.base + (x.elem_offset(n, h + t / 3 - 1, w + t % 3 - 1) + ci) * (int64_t)sizeof(T));
+#pragma unroll
+          for (int j = 0; j < CH; ++j) acc[t][j] = fmaf(xv, g[j], acc[t][j]);
+        }
+      }
+    }
+    // lanes with equal (lane % cpp) own the same channels
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        float v = acc[t][j];
+        for (int o = cpp; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+        acc[t][j] = v;
+      }
+    if (lane < cpp) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < CH; ++j) sm[((wave * cpp + lane) * 9 + t) * CH + j] = acc[t][j];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < Co * 9; o += blockDim.x) {
+      const int co = o / 9, t = o - co * 9;
+      const int occ = co / CH, j = co - occ * CH;
+      float s = 0.f;
+      for (int w4 = 0; w4 < (int)(blockDim.x >> 6); ++w4) s += sm[((w4 * cpp + occ) * 9 + t) * CH + j];
+      part[(int64_t)blockIdx.x * (Co * Ci * 9) + ((int64_t)co * Ci + ci) * 9 + t] = s;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int insar_conv3x3_small_wgrad_blocks(int32_t B, int32_t H) {
+  int64_t r = (int64_t)B * H;
+  return (int)(r > 512 ? 512 : r);
+}
+
+extern "C" int insar_conv3x3_small_wgrad(const InsarAct* x, const InsarAct* dy, float* part, void* stream) {
+  int rc;
+  if ((rc = check_small(x, dy, "insar_conv3x3_small_wgrad"))) return rc;
+  if (!part) INSAR_FAIL(INSAR_E_ARG, "insar_conv3x3_small_wgrad: null part");
+  const int ch = dy->dtype == INSAR_BF16 ? 8 : 4;
+  const int cpp = dy->c_len / ch;
+  size_t lds = (size_t)4 * cpp * 9 * ch * sizeof(float);
+  int grid = insar_conv3x3_small_wgrad_blocks(dy->B, dy->H);
+  hipStream_t s = (hipStream_t)stream;
+  if (dy->dtype == INSAR_BF16) hipLaunchKernelGGL(conv3x3_small_wgrad_kernel<bf16_t>, dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), make_view(*dy), part);
+  else hipLaunchKernelGGL(conv3x3_small_wgrad_kernel<float>, dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), make_view(*dy), part);
+  INSAR_CHECK_LAUNCH("insar_conv3x3_small_wgrad");
+  return INSAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// outc forward: logits[n][k][h][w] = bias[k] + sum_c W[k][c] x[n,h,w,c]   (NCHW fp32 out)
+// cpp consecutive lanes share a pixel (one 16-byte chunk each) and combine with xor-shuffles.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void conv1x1_out_fwd_kernel(ActView x, const float* __restrict__ wt, const float* __restrict__ bias,
+                                       float* __restrict__ logits, int K) {
+  constexpr int CH = Chunk<T>::N;
+  extern __shared__ float sm[];                     // [K][C]
+  const int C = x.c_len;
+  for (int i = threadIdx.x; i < K * C; i += blockDim.x) sm[i] = wt[i];
+  __syncthreads();
+  const int cpp = C / CH;
+  const int rows = x.B * x.H;
+  const int total = x.W * cpp;
+  const int64_t HW = (int64_t)x.H * x.W;
+  const int cc = threadIdx.x % cpp;
+  const int tot_pad = (total + blockDim.x - 1) / blockDim.x * blockDim.x;   // keep whole waves in the shuffles
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int n = r / x.H, h = r - n * x.H;
+    for (int e = threadIdx.x; e < tot_pad; e += blockDim.x) {
+      const int w = e / cpp;
+      const bool ok = e < total;
+      float f[CH];
+      if (ok) Chunk<T>::unpack(*(const uint4*)(x.base + (x.elem_offset(n, h, w) + (int64_t)cc * CH) * (int64_t)sizeof(T)), f);
+      else {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) f[j] = 0.f;
+      }
+      for (int k = 0; k < K; ++k) {
+        float a = 0.f;
+        const float* wr = sm + k * C + cc * CH;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) a = fmaf(f[j], wr[j], a);
+        for (int o = 1; o < cpp; o <<= 1) a += __shfl_xor(a, o, 64);
+        if (ok && cc == 0) logits[((int64_t)n * K + k) * HW + (int64_t)h * x.W + w] = a + (bias ? bias[k] : 0.f);
+      }
+    }
+  }
+}
+
+static int check_out(const InsarAct* x, int K, const char* who) {
+  int rc;
+  if ((rc = insar_check_act(x, who, "x"))) return rc;
+  const int ch = x->dtype == INSAR_BF16 ? 8 : 4;
+  const int cpp = x->c_len / ch;
+  if (cpp < 1 || cpp > 64 || (cpp & (cpp - 1))) INSAR_FAIL(INSAR_E_SHAPE, "%s: C=%d unsupported", who, x->c_len);
+  if (K < 1 || K > DR_MAXK) INSAR_FAIL(INSAR_E_SHAPE, "%s: num_classes=%d must be 1..%d", who, K, DR_MAXK);
+  return INSAR_OK;
+}
+
+extern "C" int insar_conv1x1_out_fwd(const InsarAct* x, const float* w, const float* bias, float* logits, int32_t K, void* stream) {
+  int rc;
+  if ((rc = check_out(x, K, "insar_conv1x1_out_fwd"))) return rc;
+  if (!w || !logits) INSAR_FAIL(INSAR_E_ARG, "insar_conv1x1_out_fwd: null pointer");
+  size_t lds = (size_t)K * x->c_len * sizeof(float);
+  int grid = insar_grid_cap((int64_t)x->B * x->H);
+  hipStream_t s = (hipStream_t)stream;
+  if (x->dtype == INSAR_BF16) hipLaunchKernelGGL(conv1x1_out_fwd_kernel<bf16_t>, dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), w, bias, logits, K);
+  else hipLaunchKernelGGL(conv1x1_out_fwd_kernel<float>, dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), w, bias, logits, K);
+  INSAR_CHECK_LAUNCH("insar_conv1x1_out_fwd");
+  return INSAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// outc backward: dx[n,h,w,c] = sum_k dl[n,k,h,w] W[k][c];  dW[k][c] = sum dl*x;  db[k] = sum dl
+// part[block][K*C + K] partial sums (one row per block), folded by insar_colsum.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void conv1x1_out_bwd_kernel(ActView x, const float* __restrict__ wt, const float* __restrict__ dl,
+                                       int K, ActView dx, float* __restrict__ part) {
+  constexpr int CH = Chunk<T>::N;
+  extern __shared__ float sm[];                     // [K][C] weights, then [4][K*C + K] partials
+  const int C = x.c_len;
+  float* sw = sm;
+  float* sp = sm + K * C;
+  for (int i = threadIdx.x; i < K * C; i += blockDim.x) sw[i] = wt[i];
+  __syncthreads();
+  const int cpp = C / CH;
+  const int rows = x.B * x.H;
+  const int total = x.W * cpp;
+  const int64_t HW = (int64_t)x.H * x.W;
+  const int cc = threadIdx.x % cpp;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float aw[DR_MAXK][CH], ab[DR_MAXK];
+#pragma unroll
+  for (int k = 0; k < DR_MAXK; ++k) {
+    ab[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) aw[k][j] = 0.f;
+  }
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int n = r / x.H, h = r - n * x.H;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+      const int w = e / cpp;
+      float f[CH], o[CH];
+      Chunk<T>::unpack(*(const uint4*)(x.base + (x.elem_offset(n, h, w) + (int64_t)cc * CH) * (int64_t)sizeof(T)), f);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) o[j] = 0.f;
+#pragma unroll
+      for (int k = 0; k < DR_MAXK; ++k) {
+        if (k < K) {
+          const float g = dl[((int64_t)n * K + k) * HW + (int64_t)h * x.W + w];
+          const float* wr = sw + k * C + cc * CH;
+#pragma unroll
+          for (int j = 0; j < CH; ++j) { o[j] = fmaf(g, wr[j], o[j]); aw[k][j] = fmaf(g, f[j], aw[k][j]); }
+          if (cc == 0) ab[k] += g;
+        }
+      }
+      *(uint4*)(dx.base + (dx.elem_offset(n, h, w) + (int64_t)cc * CH) * (int64_t)sizeof(T)) = Chunk<T>::pack(o);
+    }
+  }
+  const int pw = K * C + K;
+#pragma unroll
+  for (int k = 0; k < DR_MAXK; ++k) {
+    if (k < K) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        float v = aw[k][j];
+        for (int o = cpp; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+        if (lane < cpp) sp[wave * pw + k * C + lane * CH + j] = v;
+      }
+      float b = ab[k];
+      for (int o = 1; o < 64; o <<= 1) b += __shfl_xor(b, o, 64);
+      if (lane == 0) sp[wave * pw + K * C + k] = b;
+    }
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < pw; o += blockDim.x) {
+    float s = 0.f;
+    for (int w4 = 0; w4 < (int)(blockDim.x >> 6); ++w4) s += sp[w4 * pw + o];
+    part[(int64_t)blockIdx.x * pw + o] = s;
+  }
+}
+
+extern "C" int insar_conv1x1_out_bwd_blocks(int32_t B, int32_t H) {
+  int64_t r = (int64_t)B * H;
+  return (int)(r > 1024 ? 1024 : r);
+}
+
+extern "C" int insar_conv1x1_out_bwd(const InsarAct* x, const float* w, const float* dlogits, int32_t K,
+                                     const InsarAct* dx, float* part, void* stream) {
+  int rc;
+  if ((rc = check_out(x, K, "insar_conv1x1_out_bwd"))) return rc;
+  if ((rc = insar_check_act(dx, "insar_conv1x1_out_bwd", "dx"))) return rc;
+  if (!w || !dlogits || !part) INSAR_FAIL(INSAR_E_ARG, "insar_conv1x1_out_bwd: null pointer");
+  if (x->B != dx->B || x->H != dx->H || x->W != dx->W || x->c_len != dx->c_len || x->dtype != dx->dtype)
+    INSAR_FAIL(INSAR_E_SHAPE, "insar_conv1x1_out_bwd: x/dx mismatch");
+  size_t lds = (size_t)(K * x->c_len + 4 * (K * x->c_len + K)) * sizeof(float);
+  int grid = insar_conv1x1_out_bwd_blocks(x->B, x->H);
+  hipStream_t s = (hipStream_t)stream;
+  if (x->dtype == INSAR_BF16) hipLaunchKernelGGL(conv1x1_out_bwd_kernel<bf16_t>, dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), w, dlogits, K, make_view(*dx), part);
+  else hipLaunchKernelGGL(conv1x1_out_bwd_kernel<float>, dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), w, dlogits, K, make_view(*dx), part);
+  INSAR_CHECK_LAUNCH("insar_conv1x1_out_bwd");
+  return INSAR_OK;
+}

@@ -1,0 +1,315 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores.
+//
+//   Y[m, n] = sum_{tap} sum_{k} X[in_pix(m, tap), k] * Wt[tap][n][k]
+//
+// replaces nn.Conv2d(3x3, pad 1) forward (Unet-ChannalAttention.py:81,84), its input-gradient
+// (same kernel, flipped taps + transposed weights), nn.ConvTranspose2d(k2,s2) forward
+// (:112-121; one tap, N = 4*Cout, scatter epilogue) and its input-gradient (4 taps, stride 2).
+//
+// Design (CDNA4):
+//  * activations are NHWC with a zero halo, so every tap of every output pixel is an in-bounds,
+//    channel-contiguous 128-byte row segment: A rows are gathered straight into LDS by LDS-DMA
+//    (global_load_lds_dwordx4, per-lane source address = pixel row + tap offset).
+//  * 128(M pixels) x BN(out channels) x 128-byte K slabs, double-buffered in LDS; 4 waves (2x2),
+//    each owning 64 x BN/2 of the tile as 16x16 MFMA tiles. LDS rows are XOR-swizzled on the
+//    DMA *source* address (chunk ^= row & 7) so the ds_read_b128 fragment reads are conflict-free.
+//  * MFMA A operand = weights, B operand = activations, so each lane ends up holding 4 consecutive
+//    output channels of one pixel; the tile is transposed through LDS and stored as full 16-byte
+//    channel chunks (NHWC rows), and the per-channel sum / sum-of-squares partials that
+//    BatchNorm needs (:82,85) are taken from the *stored* values on the way out (one slab row per
+//    M tile, no atomics).
+//  * bf16: v_mfma_f32_16x16x32_bf16 (fp32 accumulate); fp32: v_mfma_f32_16x16x4_f32 (exact fp32).
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define IG_BM 128
+#define IG_THREADS 256
+#define IG_ROWB 128  // bytes of K per LDS row
+
+struct IgemmArgs {
+  const char* x; const char* w; char* y; const float* bias; float* stats;
+  long long M;
+  int Ho, Wo, stride;
+  int Hi, Wi, Cx, cx_off, K;
+  int Hy, Wy, Cy, cy_off;
+  int N, ntaps, mode, Cout;
+  int kc_per_tap;
+  int num_mtiles, num_ntiles;
+  int tapoff[12];  // element offset of each tap relative to the tap-(0,0) pixel
+};
+
+__device__ __forceinline__ void lds_dma16(const char* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  __device__ __forceinline__ static void run(const uint4& wa, const uint4& xb, f32x4_t& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, xb), acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  __device__ __forceinline__ static void run(const uint4& wa, const uint4& xb, f32x4_t& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.x), __uint_as_float(xb.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.y), __uint_as_float(xb.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.z), __uint_as_float(xb.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.w), __uint_as_float(xb.w), acc, 0, 0, 0);
+  }
+};
+
+template <typename T, int BN>
+struct IgemmCfg {
+  static constexpr int ES = sizeof(T);
+  static constexpr int BKe = IG_ROWB / ES;
+  static constexpr int A_STAGE = IG_BM * IG_ROWB;
+  static constexpr int B_STAGE = BN * IG_ROWB;
+  static constexpr int STAGE = A_STAGE + B_STAGE;
+  static constexpr int PITCH = BN * ES + 16;              // epilogue tile row pitch (bytes)
+  static constexpr int TILE = IG_BM * PITCH;
+  static constexpr int MAIN = (2 * STAGE > TILE) ? 2 * STAGE : TILE;
+  static constexpr int ROWINFO = IG_BM * 8 * 2;           // rowIn[128], rowOut[128] (int64)
+  static constexpr int STATB = 4 * BN * 2 * 4;            // per-wave channel partials
+  static constexpr int TAPB = 64;                          // tap offsets (12 ints)
+  static constexpr int LDS_BYTES = MAIN + ROWINFO + STATB + TAPB;
+};
+
+template <typename T, int BN>
+__global__ __launch_bounds__(IG_THREADS, 2) void igemm_kernel(IgemmArgs a) {
+  using Cfg = IgemmCfg<T, BN>;
+  constexpr int ES = Cfg::ES, BKe = Cfg::BKe, CH = Chunk<T>::N;
+  constexpr int NT = BN / 32, MT = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  long long* rowIn = (long long*)(smem + Cfg::MAIN);
+  long long* rowOut = rowIn + IG_BM;
+  float* sstat = (float*)(smem + Cfg::MAIN + Cfg::ROWINFO);
+  int* stap = (int*)(smem + Cfg::MAIN + Cfg::ROWINFO + Cfg::STATB);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware tile order: blocks that share an XCD (blockIdx % 8) get consecutive tiles, so the
+  // A rows / halo rows shared by neighbouring tiles hit in that XCD's L2 (bijective remap).
+  int t;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int mtile = t / a.num_ntiles, ntile = t - mtile * a.num_ntiles;
+  const long long m0 = (long long)mtile * IG_BM;
+  const int n0 = ntile * BN;
+
+  if (tid == IG_THREADS - 1) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) stap[i] = a.tapoff[i];
+  }
+  if (tid < IG_BM) {
+    const long long m = m0 + tid;
+    const bool valid = m < a.M;
+    const long long mm = valid ? m : 0;
+    const long long hw = (long long)a.Ho * a.Wo;
+    const int n = (int)(mm / hw);
+    const int rem = (int)(mm - (long long)n * hw);
+    const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+    rowIn[tid] = (((long long)n * (a.Hi + 2) + ho * a.stride + 1) * (a.Wi + 2) + wo * a.stride + 1) * a.Cx + a.cx_off;
+    const int so = a.mode == 1 ? 2 : 1;
+    const long long ro = (((long long)n * (a.Hy + 2) + ho * so + 1) * (a.Wy + 2) + wo * so + 1) * a.Cy + a.cy_off;
+    rowOut[tid] = valid ? ro : -1;
+  }
+  __syncthreads();
+
+  // per-thread staging geometry: chunk q = i*256 + tid -> LDS row q>>3, lane-linear position q&7
+  const int srow = tid >> 3;                       // + 32*i
+  const int schunk = ((tid & 7) ^ (srow & 7)) * 16; // swizzled source chunk (bytes)
+  long long a_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_src[i] = rowIn[srow + 32 * i] * ES + schunk;
+  const long long b_row_bytes = (long long)a.K * ES;
+  const int nk = a.ntaps * a.kc_per_tap;
+
+  auto stage = [&](int buf, int ks) {
+    const int tap = ks / a.kc_per_tap;
+    const int kc = ks - tap * a.kc_per_tap;
+    const char* xb = a.x + ((long long)stap[tap] + (long long)kc * BKe) * ES;
+    char* la = smem + buf * Cfg::STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lds_dma16(xb + a_src[i], la + i * 4096);
+    const char* wb = a.w + (((long long)tap * a.N + n0 + srow) * a.K + (long long)kc * BKe) * ES + schunk;
+    char* lb = smem + buf * Cfg::STAGE + Cfg::A_STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) lds_dma16(wb + (long long)i * 32 * b_row_bytes, lb + i * 4096);
+  };
+
+  f32x4_t acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int wm = wave & 1, wn = wave >> 1;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int a_frag = (wm * 64 + r16) * IG_ROWB;            // + mt*16*128
+  const int b_frag = (wn * (BN / 2) + r16) * IG_ROWB;      // + nt*16*128
+  const int sw = r16 & 7;
+
+  stage(0, 0);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int buf = ks & 1;
+    if (ks + 1 < nk) stage(buf ^ 1, ks + 1);
+    const char* sA = smem + buf * Cfg::STAGE;
+    const char* sB = sA + Cfg::A_STAGE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int pc = ((kq + 4 * s) ^ sw) * 16;
+      uint4 xf[MT], wf[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) xf[mt] = *(const uint4*)(sA + a_frag + mt * 16 * IG_ROWB + pc);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) wf[nt] = *(const uint4*)(sB + b_frag + nt * 16 * IG_ROWB + pc);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) Mma<T>::run(wf[nt], xf[mt], acc[nt][mt]);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: registers -> LDS tile [pixel][channel] -> 16-byte NHWC stores (+stats) ----------
+  char* tile = smem;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = wm * 64 + mt * 16 + r16;
+      const int col = wn * (BN / 2) + nt * 16 + kq * 4;
+      char* p = tile + row * Cfg::PITCH + col * ES;
+      if constexpr (ES == 2) {
+        uint2 v;
+        v.x = (uint32_t)f32_to_bf16(acc[nt][mt][0]) | ((uint32_t)f32_to_bf16(acc[nt][mt][1]) << 16);
+        v.y = (uint32_t)f32_to_bf16(acc[nt][mt][2]) | ((uint32_t)f32_to_bf16(acc[nt][mt][3]) << 16);
+        *(uint2*)p = v;
+      } else {
+        *(f32x4_t*)p = acc[nt][mt];
+      }
+    }
+  __syncthreads();
+
+  constexpr int CPR = BN * ES / 16;               // 16-byte chunks per tile row
+  constexpr int ITER = IG_BM * CPR / IG_THREADS;
+  constexpr int RSTEP = IG_THREADS / CPR;
+  const int cc = tid % CPR;
+  const int ncol = n0 + cc * CH;
+  float bias[CH];
+  int bias_base = ncol;
+  long long col_off = ncol;                        // mode 0: channel offset inside the pixel
+  if (a.mode == 1) {
+    const int q4 = ncol / a.Cout;
+    const int co = ncol - q4 * a.Cout;
+    bias_base = co;
+    col_off = ((long long)(q4 >> 1) * (a.Wy + 2) + (q4 & 1)) * a.Cy + co;
+  }
+#pragma unroll
+  for (int j = 0; j < CH; ++j) bias[j] = a.bias ? a.bias[bias_base + j] : 0.f;
+  float s1[CH], s2[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < ITER; ++i) {
+    const int row = i * RSTEP + tid / CPR;
+    const long long ro = rowOut[row];
+    if (ro >= 0) {
+      float f[CH];
+      Chunk<T>::unpack(*(const uint4*)(tile + row * Cfg::PITCH + cc * 16), f);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { s1[j] += f[j]; s2[j] = fmaf(f[j], f[j], s2[j]); f[j] += bias[j]; }
+      *(uint4*)(a.y + (ro + col_off) * ES) = Chunk<T>::pack(f);
+    }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+#pragma unroll
+      for (int o = CPR; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+    }
+    if (lane < CPR) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        sstat[(wave * BN + lane * CH + j) * 2 + 0] = s1[j];
+        sstat[(wave * BN + lane * CH + j) * 2 + 1] = s2[j];
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { v1 += sstat[(w * BN + tid) * 2 + 0]; v2 += sstat[(w * BN + tid) * 2 + 1]; }
+      a.stats[((long long)mtile * 2 + 0) * a.N + n0 + tid] = v1;
+      a.stats[((long long)mtile * 2 + 1) * a.N + n0 + tid] = v2;
+    }
+  }
+}
+
+extern "C" int insar_igemm_num_mtiles(int64_t M) { return (int)((M + IG_BM - 1) / IG_BM); }
+
+template <typename T, int BN>
+static int launch_igemm(const IgemmArgs& a, hipStream_t s) {
+  using Cfg = IgemmCfg<T, BN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<T, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_igemm: hipFuncSetAttribute(%d bytes LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int grid = a.num_mtiles * a.num_ntiles;
+  hipLaunchKernelGGL((igemm_kernel<T, BN>), dim3(grid), dim3(IG_THREADS), Cfg::LDS_BYTES, s, a);
+  INSAR_CHECK_LAUNCH("insar_igemm");
+  return INSAR_OK;
+}
+
+extern "C" int insar_igemm(const InsarIgemm* d, void* stream) {
+  if (!d || !d->x.ptr || !d->y.ptr || !d->w) INSAR_FAIL(INSAR_E_ARG, "insar_igemm: null pointer");
+  int rc;
+  if ((rc = insar_check_act(&d->x, "insar_igemm", "x"))) return rc;
+  if ((rc = insar_check_act(&d->y, "insar_igemm", "y"))) return rc;
+  if (d->x.dtype != d->y.dtype) INSAR_FAIL(INSAR_E_DTYPE, "insar_igemm: x/y dtype differ");
+  const int es = d->x.dtype == INSAR_BF16 ? 2 : 4;
+  const int bke = IG_ROWB / es;
+  const int K = d->x.c_len;
+  if (K % bke) INSAR_FAIL(INSAR_E_SHAPE, "insar_igemm: K=%d must be a multiple of %d", K, bke);
+  if (d->N % 64) INSAR_FAIL(INSAR_E_SHAPE, "insar_igemm: N=%d must be a multiple of 64", d->N);
+  if (d->ntaps < 1 || d->ntaps > 12) INSAR_FAIL(INSAR_E_SHAPE, "insar_igemm: ntaps=%d", d->ntaps);
+  if (d->stride != 1 && d->stride != 2) INSAR_FAIL(INSAR_E_SHAPE, "insar_igemm: stride=%d", d->stride);
+  if (d->x.B != d->y.B) INSAR_FAIL(INSAR_E_SHAPE, "insar_igemm: batch differs");
+  if (!insar_aligned16(d->w)) INSAR_FAIL(INSAR_E_ALIGN, "insar_igemm: weights not 16-byte aligned");
+  int cout = d->N;
+  if (d->mode == 0) {
+    if (d->y.H != d->Ho || d->y.W != d->Wo || d->y.c_len != d->N) INSAR_FAIL(INSAR_E_SHAPE, "insar_igemm: output slice does not match Ho/Wo/N");
+  } else if (d->mode == 1) {
+    cout = d->N / 4;
+    if (d->y.H != 2 * d->Ho || d->y.W != 2 * d->Wo || d->y.c_len != cout || (cout % 8)) INSAR_FAIL(INSAR_E_SHAPE, "insar_igemm: convT output slice mismatch");
+  } else INSAR_FAIL(INSAR_E_ARG, "insar_igemm: mode=%d", d->mode);
+  // every tap of every row must stay inside the padded input
+  for (int t = 0; t < d->ntaps; ++t) {
+    const int ymin = d->dy[t], ymax = (d->Ho - 1) * d->stride + d->dy[t];
+    const int xmin = d->dx[t], xmax = (d->Wo - 1) * d->stride + d->dx[t];
+    if (ymin < -1 || xmin < -1 || ymax > d->x.H || xmax > d->x.W)
+      INSAR_FAIL(INSAR_E_SHAPE, "insar_igemm: tap %d (%d,%d) leaves the padded input", t, d->dy[t], d->dx[t]);
+  }
+  IgemmArgs a;
+  a.x = (const char*)d->x.ptr; a.w = (const char*)d->w; a.y = (char*)d->y.ptr; a.bias = d->bias; a.stats = d->stats;
+  a.M = (long long)d->x.B * d->Ho * d->Wo;
+  a.Ho = d->Ho; a.Wo = d->Wo; a.stride = d->stride;
+  a.Hi = d->x.H; a.Wi = d->x.W; a.Cx = d->x.C; a.cx_off = d->x.c_off; a.K = K;
+  a.Hy = d->y.H; a.Wy = d->y.W; a.Cy = d->y.C; a.cy_off = d->y.c_off;
+  a.N = d->N; a.ntaps = d->ntaps; a.mode = d->mode; a.Cout = cout;
+  a.kc_per_tap = K / bke;
+  a.num_mtiles = insar_igemm_num_mtiles(a.M);
+  for (int t = 0; t < 12; ++t) a.tapoff[t] = t < d->ntaps ? (d->dy[t] * (d->x.W + 2) + d->dx[t]) * d->x.C : 0;
+  hipStream_t s = (hipStream_t)stream;
+  const bool wide = (d->N % 128) == 0;
+  a.num_ntiles = d->N / (wide ? 128 : 64);
+  if (d->x.dtype == INSAR_BF16) return wide ? launch_igemm<bf16_t, 128>(a, s) : launch_igemm<bf16_t, 64>(a, s);
+  return wide ? launch_igemm<float, 128>(a, s) : launch_igemm<float, 64>(a, s);
+}

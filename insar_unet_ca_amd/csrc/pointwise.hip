@@ -1,0 +1,804 @@
+// Bandwidth-bound kernels of the U-Net-CA path: layout conversion, BatchNorm(+ReLU) apply /
+// finalize / backward, SE squeeze + excitation, MaxPool2d(2), partial-sum reductions.
+// All are HBM-bound: 16-byte vector accesses, one block per image row, per-channel constants
+// hoisted out of the pixel loop, partial sums written as slabs (no float atomics, so results
+// are bitwise reproducible).
+#include "common.h"
+
+#define PW_THREADS 256
+
+// One block walks image rows r = (n, h); a thread walks 16-byte chunks e of the row:
+// w = e / cpp, cc = e % cpp (cpp = chunks per pixel of the slice).
+struct RowIter {
+  int n, h;
+};
+
+template <typename T>
+__device__ __forceinline__ const uint4* chunk_ptr(const ActView& v, int n, int h, int w, int cc) {
+  return (const uint4*)(v.base + (v.elem_offset(n, h, w) + (int64_t)cc * Chunk<T>::N) * (int64_t)sizeof(T));
+}
+template <typename T>
+__device__ __forceinline__ uint4* chunk_ptr_w(const ActView& v, int n, int h, int w, int cc) {
+  return (uint4*)(v.base + (v.elem_offset(n, h, w) + (int64_t)cc * Chunk<T>::N) * (int64_t)sizeof(T));
+}
+
+// ---------------------------------------------------------------------------------------------
+// pack / unpack (nn.Module boundary)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_scalar_kernel(const float* __restrict__ src, ActView dst, int Csrc) {
+  // thread per pixel, loops channels; used when c_len is not a multiple of the chunk width
+  const int64_t HW = (int64_t)dst.H * dst.W;
+  const int64_t total = (int64_t)dst.B * HW;
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+    int n = (int)(p / HW);
+    int64_t rem = p - (int64_t)n * HW;
+    int h = (int)(rem / dst.W), w = (int)(rem - (int64_t)h * dst.W);
+    T* out = (T*)(dst.base + dst.elem_offset(n, h, w) * (int64_t)sizeof(T));
+    for (int c = 0; c < Csrc; ++c) {
+      float v = src[((int64_t)n * Csrc + c) * HW + rem];
+      if constexpr (sizeof(T) == 2) ((uint16_t*)out)[c] = f32_to_bf16(v);
+      else ((float*)out)[c] = v;
+    }
+  }
+}
+
+template <typename T>
+__global__ void pack_chunk_kernel(const float* __restrict__ src, ActView dst) {
+  constexpr int CH = Chunk<T>::N;
+  const int cpp = dst.c_len / CH;
+  const int64_t HW = (int64_t)dst.H * dst.W;
+  const int rows = dst.B * dst.H;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int n = r / dst.H, h = r - n * dst.H;
+    const int total = dst.W * cpp;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+      const int cc = e / dst.W, w = e - cc * dst.W;   // w fastest: coalesced plane reads
+      float f[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j)
+        f[j] = src[((int64_t)n * dst.c_len + cc * CH + j) * HW + (int64_t)h * dst.W + w];
+      *chunk_ptr_w<T>(dst, n, h, w, cc) = Chunk<T>::pack(f);
+    }
+  }
+}
+
+template <typename T>
+__global__ void unpack_kernel(ActView src, float* __restrict__ dst) {
+  const int64_t HW = (int64_t)src.H * src.W;
+  const int rows = src.B * src.H;
+  constexpr int CH = Chunk<T>::N;
+  if (src.c_len % CH == 0) {
+    const int cpp = src.c_len / CH;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+      const int n = r / src.H, h = r - n * src.H;
+      const int total = src.W * cpp;
+      for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int cc = e / src.W, w = e - cc * src.W;
+        float f[CH];
+        Chunk<T>::unpack(*chunk_ptr<T>(src, n, h, w, cc), f);
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+          dst[((int64_t)n * src.c_len + cc * CH + j) * HW + (int64_t)h * src.W + w] = f[j];
+      }
+    }
+  } else {
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+      const int n = r / src.H, h = r - n * src.H;
+      for (int e = threadIdx.x; e < src.W * src.c_len; e += blockDim.x) {
+        const int c = e / src.W, w = e - c * src.W;
+        const T* p = (const T*)(src.base + (src.elem_offset(n, h, w) + c) * (int64_t)sizeof(T));
+        float v;
+        if constexpr (sizeof(T) == 2) v = bf16_to_f32(*(const uint16_t*)p); else v = *(const float*)p;
+        dst[((int64_t)n * src.c_len + c) * HW + (int64_t)h * src.W + w] = v;
+      }
+    }
+  }
+}
+
+extern "C" int insar_pack_nchw(const float* src, const InsarAct* dst, void* stream) {
+  if (!src || !dst || !dst->ptr) INSAR_FAIL(INSAR_E_ARG, "insar_pack_nchw: null pointer");
+  ActView v = make_view(*dst);
+  const int ch = dst->dtype == INSAR_BF16 ? 8 : 4;
+  hipStream_t s = (hipStream_t)stream;
+  if (dst->c_len % ch == 0 && dst->c_off % ch == 0 && dst->C % ch == 0) {
+    int grid = insar_grid_cap((int64_t)dst->B * dst->H);
+    if (dst->dtype == INSAR_BF16) hipLaunchKernelGGL(pack_chunk_kernel<bf16_t>, dim3(grid), dim3(PW_THREADS), 0, s, src, v);
+    else hipLaunchKernelGGL(pack_chunk_kernel<float>, dim3(grid), dim3(PW_THREADS), 0, s, src, v);
+  } else {
+    int64_t total = (int64_t)dst->B * dst->H * dst->W;
+    int grid = insar_grid_cap((total + PW_THREADS - 1) / PW_THREADS);
+    if (dst->dtype == INSAR_BF16) hipLaunchKernelGGL(pack_scalar_kernel<bf16_t>, dim3(grid), dim3(PW_THREADS), 0, s, src, v, dst->c_len);
+    else hipLaunchKernelGGL(pack_scalar_kernel<float>, dim3(grid), dim3(PW_THREADS), 0, s, src, v, dst->c_len);
+  }
+  INSAR_CHECK_LAUNCH("insar_pack_nchw");
+  return INSAR_OK;
+}
+
+extern "C" int insar_unpack_nchw(const InsarAct* src, float* dst, void* stream) {
+  if (!src || !dst || !src->ptr) INSAR_FAIL(INSAR_E_ARG, "insar_unpack_nchw: null pointer");
+  ActView v = make_view(*src);
+  int grid = insar_grid_cap((int64_t)src->B * src->H);
+  hipStream_t s = (hipStream_t)stream;
+  if (src->dtype == INSAR_BF16) hipLaunchKernelGGL(unpack_kernel<bf16_t>, dim3(grid), dim3(PW_THREADS), 0, s, v, dst);
+  else hipLaunchKernelGGL(unpack_kernel<float>, dim3(grid), dim3(PW_THREADS), 0, s, v, dst);
+  INSAR_CHECK_LAUNCH("insar_unpack_nchw");
+  return INSAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight re-layout: out[(t*N + n)*K + k] = cast(in[t*st + n*sn + k*sk]); LDS-tiled transpose so
+// both the strided reads and the K-contiguous writes stay coalesced.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void weight_prep_kernel(const float* __restrict__ in, T* __restrict__ out, int N, int K,
+                                   int64_t st, int64_t sn, int64_t sk) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z;
+  const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
+  const bool k_fast_in = sk <= sn;                           // which index is contiguous-ish in `in`
+  for (int j = ty; j < 32; j += 8) {
+    int n = k_fast_in ? n0 + j : n0 + tx;
+    int k = k_fast_in ? k0 + tx : k0 + j;
+    float v = 0.f;
+    if (n < N && k < K) v = in[(int64_t)t * st + (int64_t)n * sn + (int64_t)k * sk];
+    if (k_fast_in) tile[j][tx] = v; else tile[tx][j] = v;   // tile[n_local][k_local]
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int n = n0 + j, k = k0 + tx;
+    if (n < N && k < K) {
+      float v = tile[j][tx];
+      int64_t o = ((int64_t)t * N + n) * K + k;
+      if constexpr (sizeof(T) == 2) ((uint16_t*)out)[o] = f32_to_bf16(v); else ((float*)out)[o] = v;
+    }
+  }
+}
+
+extern "C" int insar_weight_prep(const float* in, void* out, int32_t dtype, int32_t T, int32_t N, int32_t K,
+                                 int64_t st, int64_t sn, int64_t sk, void* stream) {
+  if (!in || !out) INSAR_FAIL(INSAR_E_ARG, "insar_weight_prep: null pointer");
+  if (T < 1 || N < 1 || K < 1 || T > 65535) INSAR_FAIL(INSAR_E_SHAPE, "insar_weight_prep: bad T/N/K %d/%d/%d", T, N, K);
+  dim3 grid((K + 31) / 32, (N + 31) / 32, T);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == INSAR_BF16) hipLaunchKernelGGL(weight_prep_kernel<bf16_t>, grid, dim3(256), 0, s, in, (bf16_t*)out, N, K, st, sn, sk);
+  else if (dtype == INSAR_F32) hipLaunchKernelGGL(weight_prep_kernel<float>, grid, dim3(256), 0, s, in, (float*)out, N, K, st, sn, sk);
+  else INSAR_FAIL(INSAR_E_DTYPE, "insar_weight_prep: dtype %d", dtype);
+  INSAR_CHECK_LAUNCH("insar_weight_prep");
+  return INSAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// segmented column sums of partial slabs: out[s][c] (+)= sum_{r in split} part[s][r][c]
+// grid = (col blocks of 64, row splits, segments); block = 64 cols x 4 row lanes.
+// ---------------------------------------------------------------------------------------------
+__global__ void colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t rows,
+                              int cols, int rows_per_split, int accumulate, int64_t out_split_stride) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int lane_r = threadIdx.x >> 6;
+  const int split = blockIdx.y, seg = blockIdx.z;
+  const int64_t r0 = (int64_t)split * rows_per_split;
+  int64_t r1 = r0 + rows_per_split; if (r1 > rows) r1 = rows;
+  float acc = 0.f;
+  if (c < cols) {
+    const float* p = part + ((int64_t)seg * rows) * cols + c;
+    for (int64_t r = r0 + lane_r; r < r1; r += 4) acc += p[r * cols];
+  }
+  red[lane_r][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (lane_r == 0 && c < cols) {
+    float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    float* o = out + (int64_t)split * out_split_stride + (int64_t)seg * cols + c;
+    if (accumulate) v += *o;
+    *o = v;
+  }
+}
+
+// Two-stage when there are many rows: stage 1 writes [nsplit][segments][cols] into `tmp`
+// (caller-provided, may be null when rows <= 256), stage 2 folds the splits.
+extern "C" int insar_colsum(const float* part, float* out, int32_t segments, int64_t rows, int32_t cols,
+                            int32_t accumulate, float* tmp, int64_t tmp_floats, void* stream) {
+  if (!part || !out) INSAR_FAIL(INSAR_E_ARG, "insar_colsum: null pointer");
+  if (segments < 1 || rows < 1 || cols < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_colsum: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const int cb = (cols + 63) / 64;
+  if (rows <= 256 || !tmp) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(cb, 1, segments), dim3(256), 0, s, part, out, rows, cols,
+                       (int)(rows > 0x7fffffff ? 0x7fffffff : rows), accumulate, (int64_t)0);
+    INSAR_CHECK_LAUNCH("insar_colsum");
+    return INSAR_OK;
+  }
+  int rps = 128;
+  int64_t nsplit = (rows + rps - 1) / rps;
+  while (nsplit > 512) { rps *= 2; nsplit = (rows + rps - 1) / rps; }
+  if (nsplit * segments * (int64_t)cols > tmp_floats)
+    INSAR_FAIL(INSAR_E_WS, "insar_colsum: tmp too small (%lld < %lld floats)", (long long)tmp_floats,
+               (long long)(nsplit * segments * (int64_t)cols));
+  hipLaunchKernelGGL(colsum_kernel, dim3(cb, (int)nsplit, segments), dim3(256), 0, s, part, tmp, rows, cols, rps,
+                     0, (int64_t)segments * cols);
+  // stage 2: treat tmp as [1 segment][nsplit rows][segments*cols]
+  const int cols2 = segments * cols;
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols2 + 63) / 64, 1, 1), dim3(256), 0, s, tmp, out, nsplit, cols2,
+                     (int)nsplit, accumulate, (int64_t)0);
+  INSAR_CHECK_LAUNCH("insar_colsum");
+  return INSAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm finalize (Unet-ChannalAttention.py:82,85; nn.BatchNorm2d training/eval semantics)
+// sums[0][c] = sum y_raw, sums[1][c] = sum y_raw^2 over `count` pixels (y_raw = conv w/o bias).
+// ---------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(InsarBnFinalize d) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && d.training && d.num_batches_tracked) *d.num_batches_tracked += 1;
+  if (c >= d.C) return;
+  const float cb = d.conv_bias ? d.conv_bias[c] : 0.f;
+  float mean_raw, invstd;
+  if (d.training) {
+    const double n = (double)d.count;
+    const double s1 = d.part[c], s2 = d.part[d.C + c];
+    const double m = s1 / n;
+    double var = s2 / n - m * m;
+    if (var < 0) var = 0;
+    mean_raw = (float)m;
+    invstd = (float)(1.0 / sqrt(var + (double)d.eps));
+    if (d.running_mean) {
+      const double unbiased = n > 1 ? var * n / (n - 1) : var;
+      d.running_mean[c] = (1.f - d.momentum) * d.running_mean[c] + d.momentum * (float)(m + cb);
+      d.running_var[c] = (1.f - d.momentum) * d.running_var[c] + d.momentum * (float)unbiased;
+    }
+  } else {
+    // eval: y = (y_raw + cb - running_mean) / sqrt(running_var + eps): "mean of y_raw" = rm - cb
+    mean_raw = d.running_mean[c] - cb;
+    invstd = 1.f / sqrtf(d.running_var[c] + d.eps);
+  }
+  const float sc = d.gamma[c] * invstd;
+  d.scale[c] = sc;
+  d.shift[c] = d.beta[c] - mean_raw * sc;
+  d.mean[c] = mean_raw;
+  d.invstd[c] = invstd;
+}
+
+extern "C" int insar_bn_finalize(const InsarBnFinalize* d, void* stream) {
+  if (!d || !d->gamma || !d->beta || !d->scale || !d->shift || !d->mean || !d->invstd)
+    INSAR_FAIL(INSAR_E_ARG, "insar_bn_finalize: null pointer");
+  if (d->training && (!d->part || d->count < 1)) INSAR_FAIL(INSAR_E_ARG, "insar_bn_finalize: training needs sums");
+  if (!d->training && (!d->running_mean || !d->running_var)) INSAR_FAIL(INSAR_E_ARG, "insar_bn_finalize: eval needs running stats");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->C + 127) / 128), dim3(128), 0, (hipStream_t)stream, *d);
+  INSAR_CHECK_LAUNCH("insar_bn_finalize");
+  return INSAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// z = relu(y*scale + shift) * gate[n][c]   (:82-83 / :85-86 and the SE scale :72)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void bn_relu_apply_kernel(ActView y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                     const float* __restrict__ gate, ActView dst, int relu) {
+  constexpr int CH = Chunk<T>::N;
+  const int cpp = y.c_len / CH;
+  const int rows = y.B * y.H;
+  const int total = y.W * cpp;
+  const bool inv = (blockDim.x % cpp) == 0;
+  float sc[CH], sh[CH], gt[CH];
+  int cc_loaded = -1, n_loaded = -1;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int n = r / y.H, h = r - n * y.H;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+      const int w = e / cpp, cc = e - w * cpp;
+      if (!inv || cc != cc_loaded || n != n_loaded) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          sc[j] = scale[cc * CH + j]; sh[j] = shift[cc * CH + j];
+          gt[j] = gate ? gate[(int64_t)n * y.c_len + cc * CH + j] : 1.f;
+        }
+        cc_loaded = cc; n_loaded = n;
+      }
+      float f[CH];
+      Chunk<T>::unpack(*chunk_ptr<T>(y, n, h, w, cc), f);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { const float z = fmaf(f[j], sc[j], sh[j]); f[j] = (relu ? fmaxf(z, 0.f) : z) * gt[j]; }
+      *chunk_ptr_w<T>(dst, n, h, w, cc) = Chunk<T>::pack(f);
+    }
+  }
+}
+
+static int check_same_grid(const InsarAct* a, const InsarAct* b, const char* who) {
+  if (a->B != b->B || a->H != b->H || a->W != b->W || a->c_len != b->c_len || a->dtype != b->dtype)
+    INSAR_FAIL(INSAR_E_SHAPE, "%s: mismatched activation slices", who);
+  return INSAR_OK;
+}
+
+extern "C" int insar_bn_relu_apply(const InsarAct* y, const float* scale, const float* shift, const float* gate,
+                                   const InsarAct* dst, int32_t relu, void* stream) {
+  int rc;
+  if ((rc = insar_check_act(y, "insar_bn_relu_apply", "y"))) return rc;
+  if ((rc = insar_check_act(dst, "insar_bn_relu_apply", "dst"))) return rc;
+  if ((rc = check_same_grid(y, dst, "insar_bn_relu_apply"))) return rc;
+  if (!scale || !shift) INSAR_FAIL(INSAR_E_ARG, "insar_bn_relu_apply: null scale/shift");
+  int grid = insar_grid_cap((int64_t)y->B * y->H);
+  hipStream_t s = (hipStream_t)stream;
+  if (y->dtype == INSAR_BF16) hipLaunchKernelGGL(bn_relu_apply_kernel<bf16_t>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*y), scale, shift, gate, make_view(*dst), relu);
+  else hipLaunchKernelGGL(bn_relu_apply_kernel<float>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*y), scale, shift, gate, make_view(*dst), relu);
+  INSAR_CHECK_LAUNCH("insar_bn_relu_apply");
+  return INSAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row reductions. Both produce part[(n*H + h)][2][C] per-row partial sums over w:
+//   se_squeeze      : q0 = mask,          q1 = mask * y          (mask = y*scale+shift > 0)
+//   bnrelu_bwd_reduce: q0 = dout * mask,  q1 = dout * mask * y
+// Cross-thread reduction through LDS (threads that own the same channel chunk).
+// ---------------------------------------------------------------------------------------------
+template <typename T, bool WITH_G>
+__global__ void row_reduce_kernel(ActView g, ActView y, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, float* __restrict__ part, int relu) {
+  constexpr int CH = Chunk<T>::N;
+  __shared__ float red[PW_THREADS][2 * CH + 1];
+  const int cpp = y.c_len / CH;
+  const int rows = y.B * y.H;
+  const int total = y.W * cpp;
+  const bool inv = (blockDim.x % cpp) == 0;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int n = r / y.H, h = r - n * y.H;
+    if (inv) {
+      float a0[CH], a1[CH], sc[CH], sh[CH];
+      const int cc = threadIdx.x % cpp;
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { a0[j] = 0.f; a1[j] = 0.f; sc[j] = scale[cc * CH + j]; sh[j] = shift[cc * CH + j]; }
+      for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int w = e / cpp;
+        float f[CH], gg[CH];
+        Chunk<T>::unpack(*chunk_ptr<T>(y, n, h, w, cc), f);
+        if constexpr (WITH_G) Chunk<T>::unpack(*chunk_ptr<T>(g, n, h, w, cc), gg);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const bool on = !relu || fmaf(f[j], sc[j], sh[j]) > 0.f;
+          const float m = WITH_G ? (on ? gg[j] : 0.f) : (on ? 1.f : 0.f);
+          a0[j] += m; a1[j] = fmaf(m, f[j], a1[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { red[threadIdx.x][j] = a0[j]; red[threadIdx.x][CH + j] = a1[j]; }
+      __syncthreads();
+      // thread t < cpp*CH*2 handles output element (q, c)
+      for (int o = threadIdx.x; o < 2 * y.c_len; o += blockDim.x) {
+        const int q = o / y.c_len, c = o - q * y.c_len;
+        const int occ = c / CH, j = c - occ * CH;
+        float s = 0.f;
+        for (int t = occ; t < blockDim.x; t += cpp) s += red[t][q * CH + j];
+        part[((int64_t)r * 2 + q) * y.c_len + c] = s;
+      }
+      __syncthreads();
+    } else {
+      // generic (slow) path: thread per channel
+      for (int c = threadIdx.x; c < y.c_len; c += blockDim.x) {
+        float s0 = 0.f, s1 = 0.f;
+        const float sc = scale[c], sh = shift[c];
+        for (int w = 0; w < y.W; ++w) {
+          const T* py = (const T*)(y.base + (y.elem_offset(n, h, w) + c) * (int64_t)sizeof(T));
+          float f, gg = 1.f;
+          if constexpr (sizeof(T) == 2) f = bf16_to_f32(*(const uint16_t*)py); else f = *(const float*)py;
+          if constexpr (WITH_G) {
+            const T* pg = (const T*)(g.base + (g.elem_offset(n, h, w) + c) * (int64_t)sizeof(T));
+            if constexpr (sizeof(T) == 2) gg = bf16_to_f32(*(const uint16_t*)pg); else gg = *(const float*)pg;
+          }
+          const float m = (!relu || fmaf(f, sc, sh) > 0.f) ? gg : 0.f;
+          s0 += m; s1 = fmaf(m, f, s1);
+        }
+        part[((int64_t)r * 2 + 0) * y.c_len + c] = s0;
+        part[((int64_t)r * 2 + 1) * y.c_len + c] = s1;
+      }
+    }
+  }
+}
+
+extern "C" int insar_se_squeeze(const InsarAct* y, const float* scale, const float* shift, float* part, int32_t relu,
+                                void* stream) {
+  int rc;
+  if ((rc = insar_check_act(y, "insar_se_squeeze", "y"))) return rc;
+  if (!scale || !shift || !part) INSAR_FAIL(INSAR_E_ARG, "insar_se_squeeze: null pointer");
+  int grid = insar_grid_cap((int64_t)y->B * y->H);
+  hipStream_t s = (hipStream_t)stream;
+  ActView v = make_view(*y);
+  if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, false>), dim3(grid), dim3(PW_THREADS), 0, s, v, v, scale, shift, part, relu);
+  else hipLaunchKernelGGL((row_reduce_kernel<float, false>), dim3(grid), dim3(PW_THREADS), 0, s, v, v, scale, shift, part, relu);
+  INSAR_CHECK_LAUNCH("insar_se_squeeze");
+  return INSAR_OK;
+}
+
+extern "C" int insar_bnrelu_bwd_reduce(const InsarAct* dout, const InsarAct* y, const float* scale, const float* shift,
+                                       float* part, int32_t relu, void* stream) {
+  int rc;
+  if ((rc = insar_check_act(y, "insar_bnrelu_bwd_reduce", "y"))) return rc;
+  if ((rc = insar_check_act(dout, "insar_bnrelu_bwd_reduce", "dout"))) return rc;
+  if ((rc = check_same_grid(y, dout, "insar_bnrelu_bwd_reduce"))) return rc;
+  if (!scale || !shift || !part) INSAR_FAIL(INSAR_E_ARG, "insar_bnrelu_bwd_reduce: null pointer");
+  int grid = insar_grid_cap((int64_t)y->B * y->H);
+  hipStream_t s = (hipStream_t)stream;
+  if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, true>), dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, part, relu);
+  else hipLaunchKernelGGL((row_reduce_kernel<float, true>), dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, part, relu);
+  INSAR_CHECK_LAUNCH("insar_bnrelu_bwd_reduce");
+  return INSAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SE excitation (Unet-ChannalAttention.py:54-59,65-68): one block per image.
+// pooled[n][0][c] = sum mask, pooled[n][1][c] = sum mask*y  =>  mean_hw(z) = (scale*q1 + shift*q0)/HW
+// ---------------------------------------------------------------------------------------------
+__global__ void se_excite_kernel(InsarSeFwd d) {
+  extern __shared__ float sm[];
+  float* sq = sm;            // [C]
+  float* hid = sm + d.C;     // [Cr]
+  const int n = blockIdx.x;
+  const float inv_hw = 1.f / ((float)d.H * (float)d.W);
+  for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
+    const float q0 = d.pooled[((int64_t)n * 2 + 0) * d.C + c];
+    const float q1 = d.pooled[((int64_t)n * 2 + 1) * d.C + c];
+    const float m = (d.scale[c] * q1 + d.shift[c] * q0) * inv_hw;
+    sq[c] = m;
+    d.sq[(int64_t)n * d.C + c] = m;
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  for (int j = wave; j < d.Cr; j += nw) {
+    float acc = 0.f;
+    for (int c = lane; c < d.C; c += 64) acc = fmaf(d.w1[(int64_t)j * d.C + c], sq[c], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const float hv = fmaxf(acc, 0.f);
+      hid[j] = hv;
+      d.hid[(int64_t)n * d.Cr + j] = hv;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
+    float acc = 0.f;
+    for (int j = 0; j < d.Cr; ++j) acc = fmaf(d.w2[(int64_t)c * d.Cr + j], hid[j], acc);
+    d.gate[(int64_t)n * d.C + c] = 1.f / (1.f + __expf(-acc));
+  }
+}
+
+extern "C" int insar_se_excite(const InsarSeFwd* d, void* stream) {
+  if (!d || !d->pooled || !d->scale || !d->shift || !d->w1 || !d->w2 || !d->sq || !d->hid || !d->gate)
+    INSAR_FAIL(INSAR_E_ARG, "insar_se_excite: null pointer");
+  if (d->B < 1 || d->C < 1 || d->Cr < 1 || d->C > 8192) INSAR_FAIL(INSAR_E_SHAPE, "insar_se_excite: bad shape");
+  size_t lds = (size_t)(d->C + d->Cr) * sizeof(float);
+  hipLaunchKernelGGL(se_excite_kernel, dim3(d->B), dim3(256), lds, (hipStream_t)stream, *d);
+  INSAR_CHECK_LAUNCH("insar_se_excite");
+  return INSAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward coefficients of [BN(train|eval) -> ReLU -> SE gate]
+//   red[n][0][c] = sum_hw dout*mask (P2)      red[n][1][c] = sum_hw dout*mask*y (Q)
+// stage 1 (block per image): SE MLP backward for that image, coefB[n][c] = dsq/HW, and the
+//   image's contribution to dbeta/dgamma  -> ws.
+// stage 2 (thread per channel / per weight): dgamma, dbeta, k1, k2, dW1, dW2, conv-bias grad.
+// ws layout (floats): du[B][C] | dt[B][Cr] | tb[B][C] | tg[B][C]
+// ---------------------------------------------------------------------------------------------
+struct BnSeBwdArgs {
+  InsarBnSeBwd d;
+  const float* red; const float* scale; const float* shift;
+  float* ws; float* dconv_bias; int training;
+};
+
+__global__ void bnse_bwd_stage1(BnSeBwdArgs a) {
+  extern __shared__ float sm[];
+  const InsarBnSeBwd& d = a.d;
+  float* du_s = sm;              // [C]
+  float* dt_s = sm + d.C;        // [Cr]
+  const int n = blockIdx.x;
+  float* du_g = a.ws + (int64_t)n * d.C;
+  float* dt_g = a.ws + (int64_t)d.B * d.C + (int64_t)n * d.Cr;
+  float* tb_g = a.ws + (int64_t)d.B * (d.C + d.Cr) + (int64_t)n * d.C;
+  float* tg_g = tb_g + (int64_t)d.B * d.C;
+  const float inv_hw = 1.f / ((float)d.H * (float)d.W);
+  if (d.use_se) {
+    for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
+      const float p2 = a.red[((int64_t)n * 2 + 0) * d.C + c];
+      const float q = a.red[((int64_t)n * 2 + 1) * d.C + c];
+      const float ds = a.scale[c] * q + a.shift[c] * p2;         // sum dout * z
+      const float s = d.gate[(int64_t)n * d.C + c];
+      const float du = ds * s * (1.f - s);
+      du_s[c] = du; du_g[c] = du;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (int j = wave; j < d.Cr; j += nw) {
+      float acc = 0.f;
+      for (int c = lane; c < d.C; c += 64) acc = fmaf(du_s[c], d.w2[(int64_t)c * d.Cr + j], acc);
+      acc = wave_sum(acc);
+      if (lane == 0) {
+        const float dtv = d.hid[(int64_t)n * d.Cr + j] > 0.f ? acc : 0.f;
+        dt_s[j] = dtv; dt_g[j] = dtv;
+      }
+    }
+    __syncthreads();
+  }
+  for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
+    const float p2 = a.red[((int64_t)n * 2 + 0) * d.C + c];
+    const float q = a.red[((int64_t)n * 2 + 1) * d.C + c];
+    const float mean = d.mean[c], istd = d.invstd[c];
+    const float p4 = istd * (q - mean * p2);                     // sum dout*mask*xhat
+    float s = 1.f, cb = 0.f, cnt = 0.f, p5 = 0.f;
+    if (d.use_se) {
+      float dsq = 0.f;
+      for (int j = 0; j < d.Cr; ++j) dsq = fmaf(dt_s[j], d.w1[(int64_t)j * d.C + c], dsq);
+      cb = dsq * inv_hw;
+      s = d.gate[(int64_t)n * d.C + c];
+      cnt = d.pooled[((int64_t)n * 2 + 0) * d.C + c];
+      const float sy = d.pooled[((int64_t)n * 2 + 1) * d.C + c];
+      p5 = istd * (sy - mean * cnt);
+      d.coefB[(int64_t)n * d.C + c] = cb;
+    }
+    tb_g[c] = s * p2 + cb * cnt;
+    tg_g[c] = s * p4 + cb * p5;
+  }
+}
+
+__global__ void bnse_bwd_stage2(BnSeBwdArgs a) {
+  const InsarBnSeBwd& d = a.d;
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const float* du_g = a.ws;
+  const float* dt_g = a.ws + (int64_t)d.B * d.C;
+  const float* tb_g = a.ws + (int64_t)d.B * (d.C + d.Cr);
+  const float* tg_g = tb_g + (int64_t)d.B * d.C;
+  if (tid < d.C) {
+    const int c = (int)tid;
+    float db = 0.f, dg = 0.f;
+    for (int n = 0; n < d.B; ++n) { db += tb_g[(int64_t)n * d.C + c]; dg += tg_g[(int64_t)n * d.C + c]; }
+    const float invN = 1.f / ((float)d.B * (float)d.H * (float)d.W);
+    d.k1[c] = a.training ? db * invN : 0.f;
+    d.k2[c] = a.training ? dg * invN : 0.f;
+    if (d.accumulate) { d.dgamma[c] += dg; d.dbeta[c] += db; } else { d.dgamma[c] = dg; d.dbeta[c] = db; }
+    if (a.dconv_bias) {
+      // training: sum dy == 0 exactly (batch-mean subtraction); eval: sum dy = scale * dbeta
+      const float v = a.training ? 0.f : a.scale[c] * db;
+      if (d.accumulate) a.dconv_bias[c] += v; else a.dconv_bias[c] = v;
+    }
+  }
+  if (!d.use_se) return;
+  const int64_t nw = (int64_t)d.C * d.Cr;
+  if (tid < nw) {                       // dW2[c][j] = sum_n du[n][c] * hid[n][j]
+    const int c = (int)(tid / d.Cr), j = (int)(tid - (int64_t)c * d.Cr);
+    float acc = 0.f;
+    for (int n = 0; n < d.B; ++n) acc = fmaf(du_g[(int64_t)n * d.C + c], d.hid[(int64_t)n * d.Cr + j], acc);
+    if (d.accumulate) d.dw2[tid] += acc; else d.dw2[tid] = acc;
+    // dW1[j][c] = sum_n dt[n][j] * sq[n][c]   (index tid2 = j*C + c)
+    const int j1 = (int)(tid / d.C), c1 = (int)(tid - (int64_t)j1 * d.C);
+    float acc1 = 0.f;
+    for (int n = 0; n < d.B; ++n) acc1 = fmaf(dt_g[(int64_t)n * d.Cr + j1], d.sq[(int64_t)n * d.C + c1], acc1);
+    if (d.accumulate) d.dw1[tid] += acc1; else d.dw1[tid] = acc1;
+  }
+}
+
+extern "C" int insar_bnse_bwd_coef(const InsarBnSeBwd* d, const float* red, const float* scale, const float* shift,
+                                   float* ws, float* dconv_bias, int32_t training, void* stream) {
+  if (!d || !red || !scale || !shift || !ws || !d->mean || !d->invstd || !d->dgamma || !d->dbeta || !d->k1 || !d->k2)
+    INSAR_FAIL(INSAR_E_ARG, "insar_bnse_bwd_coef: null pointer");
+  if (d->use_se && (!d->pooled || !d->sq || !d->hid || !d->gate || !d->w1 || !d->w2 || !d->dw1 || !d->dw2 || !d->coefB))
+    INSAR_FAIL(INSAR_E_ARG, "insar_bnse_bwd_coef: SE pointers missing");
+  if (d->C > 8192 || d->B < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_bnse_bwd_coef: bad shape");
+  BnSeBwdArgs a; a.d = *d; a.red = red; a.scale = scale; a.shift = shift; a.ws = ws; a.dconv_bias = dconv_bias; a.training = training;
+  hipStream_t s = (hipStream_t)stream;
+  size_t lds = (size_t)(d->C + (d->use_se ? d->Cr : 0) + 1) * sizeof(float);
+  hipLaunchKernelGGL(bnse_bwd_stage1, dim3(d->B), dim3(256), lds, s, a);
+  int64_t work = d->C;
+  if (d->use_se && (int64_t)d->C * d->Cr > work) work = (int64_t)d->C * d->Cr;
+  hipLaunchKernelGGL(bnse_bwd_stage2, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a);
+  INSAR_CHECK_LAUNCH("insar_bnse_bwd_coef");
+  return INSAR_OK;
+}
+
+// dy = scale * ( (dout*gate + coefB) * mask - k1 - xhat*k2 ),  xhat = (y - mean)*invstd
+template <typename T>
+__global__ void bnrelu_bwd_apply_kernel(ActView g, ActView y, const float* __restrict__ scale,
+                                        const float* __restrict__ shift, const float* __restrict__ mean,
+                                        const float* __restrict__ invstd, const float* __restrict__ gate,
+                                        const float* __restrict__ coefB, const float* __restrict__ k1,
+                                        const float* __restrict__ k2, ActView dy, int relu) {
+  constexpr int CH = Chunk<T>::N;
+  const int cpp = y.c_len / CH;
+  const int rows = y.B * y.H;
+  const int total = y.W * cpp;
+  const bool inv = (blockDim.x % cpp) == 0;
+  float sc[CH], sh[CH], mu[CH], is[CH], ga[CH], cb[CH], c1[CH], c2[CH];
+  int cc_loaded = -1, n_loaded = -1;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int n = r / y.H, h = r - n * y.H;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+      const int w = e / cpp, cc = e - w * cpp;
+      if (!inv || cc != cc_loaded || n != n_loaded) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const int c = cc * CH + j;
+          sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c]; c1[j] = k1[c]; c2[j] = k2[c];
+          ga[j] = gate ? gate[(int64_t)n * y.c_len + c] : 1.f;
+          cb[j] = coefB ? coefB[(int64_t)n * y.c_len + c] : 0.f;
+        }
+        cc_loaded = cc; n_loaded = n;
+      }
+      float f[CH], gg[CH], o[CH];
+      Chunk<T>::unpack(*chunk_ptr<T>(y, n, h, w, cc), f);
+      Chunk<T>::unpack(*chunk_ptr<T>(g, n, h, w, cc), gg);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const bool on = !relu || fmaf(f[j], sc[j], sh[j]) > 0.f;
+        const float ge = on ? fmaf(gg[j], ga[j], cb[j]) : 0.f;
+        const float xh = (f[j] - mu[j]) * is[j];
+        o[j] = sc[j] * (ge - c1[j] - xh * c2[j]);
+      }
+      *chunk_ptr_w<T>(dy, n, h, w, cc) = Chunk<T>::pack(o);
+    }
+  }
+}
+
+extern "C" int insar_bnrelu_bwd_apply(const InsarAct* dout, const InsarAct* y, const float* scale, const float* shift,
+                                      const float* mean, const float* invstd, const float* gate, const float* coefB,
+                                      const float* k1, const float* k2, const InsarAct* dy, int32_t relu, void* stream) {
+  int rc;
+  if ((rc = insar_check_act(y, "insar_bnrelu_bwd_apply", "y"))) return rc;
+  if ((rc = insar_check_act(dout, "insar_bnrelu_bwd_apply", "dout"))) return rc;
+  if ((rc = insar_check_act(dy, "insar_bnrelu_bwd_apply", "dy"))) return rc;
+  if ((rc = check_same_grid(y, dout, "insar_bnrelu_bwd_apply"))) return rc;
+  if ((rc = check_same_grid(y, dy, "insar_bnrelu_bwd_apply"))) return rc;
+  if (!scale || !shift || !mean || !invstd || !k1 || !k2) INSAR_FAIL(INSAR_E_ARG, "insar_bnrelu_bwd_apply: null pointer");
+  int grid = insar_grid_cap((int64_t)y->B * y->H);
+  hipStream_t s = (hipStream_t)stream;
+  if (y->dtype == INSAR_BF16)
+    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, mean, invstd, gate, coefB, k1, k2, make_view(*dy), relu);
+  else
+    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel<float>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, mean, invstd, gate, coefB, k1, k2, make_view(*dy), relu);
+  INSAR_CHECK_LAUNCH("insar_bnrelu_bwd_apply");
+  return INSAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool2d(2) (Unet-ChannalAttention.py:106-109). Backward routes to the first maximum in
+// scan order (0,0),(0,1),(1,0),(1,1) with torch's "val > max || isnan(val)" update rule.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool2_fwd_kernel(ActView x, ActView y) {
+  constexpr int CH = Chunk<T>::N;
+  const int cpp = y.c_len / CH;
+  const int rows = y.B * y.H;
+  const int total = y.W * cpp;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int n = r / y.H, h = r - n * y.H;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+      const int w = e / cpp, cc = e - w * cpp;
+      float a[CH], b[CH], c[CH], d[CH], o[CH];
+      Chunk<T>::unpack(*chunk_ptr<T>(x, n, 2 * h, 2 * w, cc), a);
+      Chunk<T>::unpack(*chunk_ptr<T>(x, n, 2 * h, 2 * w + 1, cc), b);
+      Chunk<T>::unpack(*chunk_ptr<T>(x, n, 2 * h + 1, 2 * w, cc), c);
+      Chunk<T>::unpack(*chunk_ptr<T>(x, n, 2 * h + 1, 2 * w + 1, cc), d);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        float m = a[j];
+        if (b[j] > m || b[j] != b[j]) m = b[j];
+        if (c[j] > m || c[j] != c[j]) m = c[j];
+        if (d[j] > m || d[j] != d[j]) m = d[j];
+        o[j] = m;
+      }
+      *chunk_ptr_w<T>(y, n, h, w, cc) = Chunk<T>::pack(o);
+    }
+  }
+}
+
+template <typename T>
+__global__ void maxpool2_bwd_kernel(ActView x, ActView dy, ActView dx, int accumulate) {
+  constexpr int CH = Chunk<T>::N;
+  const int cpp = dy.c_len / CH;
+  const int rows = dy.B * dy.H;
+  const int total = dy.W * cpp;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int n = r / dy.H, h = r - n * dy.H;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+      const int w = e / cpp, cc = e - w * cpp;
+      float v[4][CH], g[CH], o[4][CH];
+      Chunk<T>::unpack(*chunk_ptr<T>(x, n, 2 * h, 2 * w, cc), v[0]);
+      Chunk<T>::unpack(*chunk_ptr<T>(x, n, 2 * h, 2 * w + 1, cc), v[1]);
+      Chunk<T>::unpack(*chunk_ptr<T>(x, n, 2 * h + 1, 2 * w, cc), v[2]);
+      Chunk<T>::unpack(*chunk_ptr<T>(x, n, 2 * h + 1, 2 * w + 1, cc), v[3]);
+      Chunk<T>::unpack(*chunk_ptr<T>(dy, n, h, w, cc), g);
+      if (accumulate) {
+        Chunk<T>::unpack(*chunk_ptr<T>(dx, n, 2 * h, 2 * w, cc), o[0]);
+        Chunk<T>::unpack(*chunk_ptr<T>(dx, n, 2 * h, 2 * w + 1, cc), o[1]);
+        Chunk<T>::unpack(*chunk_ptr<T>(dx, n, 2 * h + 1, 2 * w, cc), o[2]);
+        Chunk<T>::unpack(*chunk_ptr<T>(dx, n, 2 * h + 1, 2 * w + 1, cc), o[3]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < CH; ++j) o[q][j] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        int best = 0; float m = v[0][j];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+          if (v[q][j] > m || v[q][j] != v[q][j]) { m = v[q][j]; best = q; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q][j] += (q == best) ? g[j] : 0.f;
+      }
+      *chunk_ptr_w<T>(dx, n, 2 * h, 2 * w, cc) = Chunk<T>::pack(o[0]);
+      *chunk_ptr_w<T>(dx, n, 2 * h, 2 * w + 1, cc) = Chunk<T>::pack(o[1]);
+      *chunk_ptr_w<T>(dx, n, 2 * h + 1, 2 * w, cc) = Chunk<T>::pack(o[2]);
+      *chunk_ptr_w<T>(dx, n, 2 * h + 1, 2 * w + 1, cc) = Chunk<T>::pack(o[3]);
+    }
+  }
+}
+
+static int check_pool(const InsarAct* x, const InsarAct* y, const char* who) {
+  if (x->B != y->B || x->H != 2 * y->H || x->W != 2 * y->W || x->c_len != y->c_len || x->dtype != y->dtype)
+    INSAR_FAIL(INSAR_E_SHAPE, "%s: pooled grid must be exactly half of the input grid", who);
+  return INSAR_OK;
+}
+
+extern "C" int insar_maxpool2_fwd(const InsarAct* x, const InsarAct* y, void* stream) {
+  int rc;
+  if ((rc = insar_check_act(x, "insar_maxpool2_fwd", "x"))) return rc;
+  if ((rc = insar_check_act(y, "insar_maxpool2_fwd", "y"))) return rc;
+  if ((rc = check_pool(x, y, "insar_maxpool2_fwd"))) return rc;
+  int grid = insar_grid_cap((int64_t)y->B * y->H);
+  hipStream_t s = (hipStream_t)stream;
+  if (x->dtype == INSAR_BF16) hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*x), make_view(*y));
+  else hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*x), make_view(*y));
+  INSAR_CHECK_LAUNCH("insar_maxpool2_fwd");
+  return INSAR_OK;
+}
+
+extern "C" int insar_maxpool2_bwd(const InsarAct* x, const InsarAct* dy, const InsarAct* dx, int32_t accumulate, void* stream) {
+  int rc;
+  if ((rc = insar_check_act(x, "insar_maxpool2_bwd", "x"))) return rc;
+  if ((rc = insar_check_act(dy, "insar_maxpool2_bwd", "dy"))) return rc;
+  if ((rc = insar_check_act(dx, "insar_maxpool2_bwd", "dx"))) return rc;
+  if ((rc = check_pool(x, dy, "insar_maxpool2_bwd"))) return rc;
+  if ((rc = check_same_grid(x, dx, "insar_maxpool2_bwd"))) return rc;
+  int grid = insar_grid_cap((int64_t)dy->B * dy->H);
+  hipStream_t s = (hipStream_t)stream;
+  if (x->dtype == INSAR_BF16) hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*x), make_view(*dy), make_view(*dx), accumulate);
+  else hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*x), make_view(*dy), make_view(*dx), accumulate);
+  INSAR_CHECK_LAUNCH("insar_maxpool2_bwd");
+  return INSAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------------
+__global__ void pixel_table_kernel(int32_t* tab, int64_t Mpad, int B, int H, int W, int s, int Hb, int Wb, int tail) {
+  const int64_t M = (int64_t)B * H * W;
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < Mpad; p += (int64_t)gridDim.x * blockDim.x) {
+    int32_t v = tail;
+    if (p < M) {
+      const int n = (int)(p / ((int64_t)H * W));
+      const int64_t rem = p - (int64_t)n * H * W;
+      const int h = (int)(rem / W), w = (int)(rem - (int64_t)h * W);
+      v = (int32_t)(((int64_t)n * (Hb + 2) + h * s + 1) * (Wb + 2) + w * s + 1);
+    }
+    tab[p] = v;
+  }
+}
+
+extern "C" int insar_pixel_table(int32_t* tab, int64_t Mpad, int32_t B, int32_t H, int32_t W, int32_t s, int32_t Hb,
+                                 int32_t Wb, int32_t tail, void* stream) {
+  if (!tab) INSAR_FAIL(INSAR_E_ARG, "insar_pixel_table: null pointer");
+  if ((int64_t)B * (Hb + 2) * (Wb + 2) > 0x7fffffffLL) INSAR_FAIL(INSAR_E_SHAPE, "insar_pixel_table: pixel index overflows int32");
+  int grid = insar_grid_cap((Mpad + 255) / 256);
+  hipLaunchKernelGGL(pixel_table_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, tab, Mpad, B, H, W, s, Hb, Wb, tail);
+  INSAR_CHECK_LAUNCH("insar_pixel_table");
+  return INSAR_OK;
+}
+
+__global__ void scale_kernel(float* p, int64_t n, float s) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] *= s;
+}
+extern "C" int insar_scale_f32(float* p, int64_t n, float s, void* stream) {
+  if (!p) INSAR_FAIL(INSAR_E_ARG, "insar_scale_f32: null pointer");
+  hipLaunchKernelGGL(scale_kernel, dim3(insar_grid_cap((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, n, s);
+  INSAR_CHECK_LAUNCH("insar_scale_f32");
+  return INSAR_OK;
+}
