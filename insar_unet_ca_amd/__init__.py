@@ -1,0 +1,9 @@
+"""insar_unet_ca_amd — MI355X-native U-Net-CA training hot path (drop-in for
+Createroner/InSAR-Unet-CA's Unet-ChannalAttention.py model/loss/optimizer entry points)."""
+from ._lib import InsarError, LIB_PATH  # noqa: F401
+from .loss import CrossEntropyLoss, DiceCELoss, DiceLoss  # noqa: F401
+from .modules import DoubleConv, MaxPool2d, SELayer, UNet  # noqa: F401
+from .optim import Adam  # noqa: F401
+
+__all__ = ["UNet", "DoubleConv", "SELayer", "MaxPool2d", "CrossEntropyLoss", "DiceLoss", "DiceCELoss", "Adam",
+           "InsarError", "LIB_PATH"]

@@ -1,0 +1,165 @@
+"""ctypes binding of libinsar_hip.so (the C ABI declared in include/insar_hip.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the shared library is
+missing (or an entry point fails) we raise, loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libinsar_hip.so")
+
+F32, BF16 = 0, 1
+ABI_VERSION = 1
+
+
+class InsarAct(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("C", C.c_int32), ("c_off", C.c_int32), ("c_len", C.c_int32), ("dtype", C.c_int32),
+                ("_pad", C.c_int32)]
+
+
+class InsarIgemm(C.Structure):
+    _fields_ = [("x", InsarAct), ("y", InsarAct), ("w", C.c_void_p), ("bias", C.c_void_p),
+                ("stats", C.c_void_p), ("N", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+                ("stride", C.c_int32), ("ntaps", C.c_int32), ("mode", C.c_int32),
+                ("dy", C.c_int8 * 12), ("dx", C.c_int8 * 12)]
+
+
+class InsarWgrad(C.Structure):
+    _fields_ = [("x", InsarAct), ("dy", InsarAct), ("tabx", C.c_void_p), ("tabdy", C.c_void_p),
+                ("part", C.c_void_p), ("Mpad", C.c_int64), ("nsplit", C.c_int32), ("ntaps", C.c_int32),
+                ("offx", C.c_int32 * 12), ("offdy", C.c_int32 * 12)]
+
+
+class InsarBnFinalize(C.Structure):
+    _fields_ = [("part", C.c_void_p), ("count", C.c_int64), ("C", C.c_int32), ("training", C.c_int32),
+                ("conv_bias", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("num_batches_tracked", C.c_void_p), ("momentum", C.c_float), ("eps", C.c_float),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p)]
+
+
+class InsarSeFwd(C.Structure):
+    _fields_ = [("pooled", C.c_void_p), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("C", C.c_int32), ("Cr", C.c_int32), ("_pad", C.c_int32),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("w1", C.c_void_p), ("w2", C.c_void_p),
+                ("sq", C.c_void_p), ("hid", C.c_void_p), ("gate", C.c_void_p)]
+
+
+class InsarBnSeBwd(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("Cr", C.c_int32),
+                ("use_se", C.c_int32),
+                ("mean", C.c_void_p), ("invstd", C.c_void_p), ("pooled", C.c_void_p), ("sq", C.c_void_p),
+                ("hid", C.c_void_p), ("gate", C.c_void_p), ("w1", C.c_void_p), ("w2", C.c_void_p),
+                ("dw1", C.c_void_p), ("dw2", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+                ("coefB", C.c_void_p), ("k1", C.c_void_p), ("k2", C.c_void_p),
+                ("accumulate", C.c_int32), ("_pad", C.c_int32)]
+
+
+_P = C.c_void_p
+_I = C.c_int32
+_L = C.c_int64
+_F = C.c_float
+_AP = C.POINTER(InsarAct)
+
+# name -> (argtypes); every function returns int except the two noted below
+_SIGNATURES = {
+    "insar_pack_nchw": [_P, _AP, _P],
+    "insar_unpack_nchw": [_AP, _P, _P],
+    "insar_weight_prep": [_P, _P, _I, _I, _I, _I, _L, _L, _L, _P],
+    "insar_igemm_num_mtiles": [_L],
+    "insar_igemm": [C.POINTER(InsarIgemm), _P],
+    "insar_wgrad": [C.POINTER(InsarWgrad), _P],
+    "insar_wgrad_reduce": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "insar_pixel_table": [_P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
+    "insar_conv3x3_small_fwd": [_AP, _P, _AP, _P, _P],
+    "insar_conv3x3_small_wgrad_blocks": [_I, _I],
+    "insar_conv3x3_small_wgrad": [_AP, _AP, _P, _P],
+    "insar_colsum": [_P, _P, _I, _L, _I, _I, _P, _L, _P],
+    "insar_bn_finalize": [C.POINTER(InsarBnFinalize), _P],
+    "insar_bn_relu_apply": [_AP, _P, _P, _P, _AP, _I, _P],
+    "insar_se_squeeze": [_AP, _P, _P, _P, _I, _P],
+    "insar_se_excite": [C.POINTER(InsarSeFwd), _P],
+    "insar_bnrelu_bwd_reduce": [_AP, _AP, _P, _P, _P, _I, _P],
+    "insar_bnse_bwd_coef": [C.POINTER(InsarBnSeBwd), _P, _P, _P, _P, _P, _I, _P],
+    "insar_bnrelu_bwd_apply": [_AP, _AP, _P, _P, _P, _P, _P, _P, _P, _P, _AP, _I, _P],
+    "insar_maxpool2_fwd": [_AP, _AP, _P],
+    "insar_maxpool2_bwd": [_AP, _AP, _AP, _I, _P],
+    "insar_conv1x1_out_fwd": [_AP, _P, _P, _P, _I, _P],
+    "insar_conv1x1_out_bwd_blocks": [_I, _I],
+    "insar_conv1x1_out_bwd": [_AP, _P, _P, _I, _AP, _P, _P],
+    "insar_ce_blocks": [_L],
+    "insar_cross_entropy": [_P, _P, _I, _I, _L, _L, _P, _P, _P, _P],
+    "insar_dice": [_P, _P, _I, _I, _L, _L, _F, _P, _P, _P, _P],
+    "insar_confusion": [_P, _P, _I, _I, _L, _L, _P, _P],
+    "insar_adam_step": [_P, _P, _I, _I, _F, _F, _F, _F, _F, _F, _F, _P],
+    "insar_scale_f32": [_P, _L, _F, _P],
+}
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["insar_version", "insar_last_error"])
+
+_lib = None
+
+
+class InsarError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libinsar_hip.so (once). Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise InsarError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU / eager fallback for the HIP path)")
+    lib = C.CDLL(LIB_PATH)
+    lib.insar_version.restype = C.c_int
+    lib.insar_version.argtypes = []
+    lib.insar_last_error.restype = C.c_char_p
+    lib.insar_last_error.argtypes = []
+    for name, args in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = args
+    if lib.insar_version() != ABI_VERSION:
+        raise InsarError(f"libinsar_hip.so ABI {lib.insar_version()} != expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+_COUNT_ONLY = {"insar_igemm_num_mtiles", "insar_conv3x3_small_wgrad_blocks", "insar_conv1x1_out_bwd_blocks",
+               "insar_ce_blocks"}
+
+
+def call(name: str, *args) -> int:
+    """Invoke an entry point; negative return codes raise InsarError(insar_last_error())."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if name in _COUNT_ONLY:
+        return rc
+    if rc != 0:
+        raise InsarError(f"{name} failed ({rc}): {lib.insar_last_error().decode(errors='replace')}")
+    return 0
+
+
+def stream_ptr() -> int:
+    """The caller's HIP stream (torch's current stream): kernels are enqueued there, never synced."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise InsarError(f"unsupported compute dtype {dt} (float32 or bfloat16)")
+
+
+def ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()

@@ -1,0 +1,564 @@
+"""Host-side execution plans for the U-Net-CA hot path.
+
+A plan owns every device buffer of one (batch, height, width, dtype) configuration
+— activations are padded NHWC (`Act`), sized once and reused every step — and turns
+`UNet.forward` / `loss.backward()` (Unet-ChannalAttention.py:127-163, :345) into a fixed
+sequence of launches through the C ABI (`_lib.call`) on torch's current HIP stream.
+PyTorch only provides device memory, streams and the autograd edge at the module boundary.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import InsarAct, InsarBnFinalize, InsarBnSeBwd, InsarIgemm, InsarSeFwd, InsarWgrad, call, ptr
+
+BN_ROW_PIX = 128        # igemm M-tile (rows of one stats slab row)
+WG_BKP = 64             # wgrad pixels per K step
+
+
+def _round_up(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+class Act:
+    """A channel slice [c_off, c_off+c_len) of a padded NHWC buffer [B][H+2][W+2][C]."""
+
+    def __init__(self, buf: torch.Tensor, B: int, H: int, W: int, Ctot: int, c_off: int, c_len: int):
+        self.buf, self.B, self.H, self.W, self.C, self.c_off, self.c_len = buf, B, H, W, Ctot, c_off, c_len
+        self.code = _lib.dtype_code(buf.dtype)
+        self.desc = InsarAct(buf.data_ptr(), B, H, W, Ctot, c_off, c_len, self.code, 0)
+        self.ref = C.byref(self.desc)
+
+    @staticmethod
+    def alloc(B, H, W, Cn, dtype, device) -> "Act":
+        nbytes = B * (H + 2) * (W + 2) * Cn * (2 if dtype == torch.bfloat16 else 4)
+        if nbytes >= 2 ** 32:
+            raise _lib.InsarError(f"activation buffer of {nbytes} bytes exceeds the 4 GiB addressing budget")
+        return Act(torch.zeros((B, H + 2, W + 2, Cn), dtype=dtype, device=device), B, H, W, Cn, 0, Cn)
+
+    def slice(self, c_off: int, c_len: int) -> "Act":
+        return Act(self.buf, self.B, self.H, self.W, self.C, self.c_off + c_off, c_len)
+
+    def nchw(self) -> torch.Tensor:
+        """Interior as a float32 NCHW tensor (debug / tests only)."""
+        v = self.buf[:, 1:-1, 1:-1, self.c_off:self.c_off + self.c_len]
+        return v.permute(0, 3, 1, 2).float().contiguous()
+
+
+class Ctx:
+    """Per-(device, dtype) shared scratch: reduction temporaries, wgrad slabs, pixel tables."""
+
+    def __init__(self, device: torch.device, dtype: torch.dtype):
+        self.device, self.dtype = device, dtype
+        self.code = _lib.dtype_code(dtype)
+        self.esize = 2 if dtype == torch.bfloat16 else 4
+        self.ch = 16 // self.esize
+        self._colsum_tmp = torch.empty(1 << 20, dtype=torch.float32, device=device)
+        self._wgrad_part: Optional[torch.Tensor] = None
+        self._tables: Dict[tuple, torch.Tensor] = {}
+        self._consts: Dict[tuple, torch.Tensor] = {}
+
+    # ---- small helpers ------------------------------------------------------------------------
+    def f32(self, *shape) -> torch.Tensor:
+        return torch.zeros(shape, dtype=torch.float32, device=self.device)
+
+    def const(self, value: float, n: int) -> torch.Tensor:
+        key = (value, n)
+        if key not in self._consts:
+            self._consts[key] = torch.full((n,), value, dtype=torch.float32, device=self.device)
+        return self._consts[key]
+
+    def colsum(self, part: torch.Tensor, out: torch.Tensor, segments: int, rows: int, cols: int,
+               accumulate: bool = False) -> None:
+        need = 0
+        if rows > 256:
+            need = ((rows + 127) // 128) * segments * cols
+            if need > self._colsum_tmp.numel():
+                self._colsum_tmp = torch.empty(need, dtype=torch.float32, device=self.device)
+        call("insar_colsum", ptr(part), ptr(out), segments, rows, cols, int(accumulate),
+             ptr(self._colsum_tmp), self._colsum_tmp.numel(), _lib.stream_ptr())
+
+    def wgrad_part(self, floats: int) -> torch.Tensor:
+        if self._wgrad_part is None or self._wgrad_part.numel() < floats:
+            self._wgrad_part = torch.empty(floats, dtype=torch.float32, device=self.device)
+        return self._wgrad_part
+
+    def pixel_table(self, B, H, W, s, Hb, Wb, tail) -> torch.Tensor:
+        key = (B, H, W, s, Hb, Wb, tail)
+        if key not in self._tables:
+            mpad = _round_up(B * H * W, WG_BKP)
+            t = torch.empty(mpad, dtype=torch.int32, device=self.device)
+            call("insar_pixel_table", ptr(t), mpad, B, H, W, s, Hb, Wb, tail, _lib.stream_ptr())
+            self._tables[key] = t
+        return self._tables[key]
+
+
+class GemmWeight:
+    """GEMM-operand copies ([tap][n][k], compute dtype) of a Conv2d / ConvTranspose2d weight,
+    refreshed when the fp32 master parameter changes (tracked by tensor version + storage)."""
+
+    def __init__(self, ctx: Ctx, param: torch.nn.Parameter, kind: str):
+        self.ctx, self.param, self.kind = ctx, param, kind
+        self._fwd = self._dgrad = None
+        self._fwd_key = self._dgrad_key = None
+
+    def _key(self):
+        return (self.param._version, self.param.data_ptr())
+
+    def _prep(self, T, N, K, st, sn, sk) -> torch.Tensor:
+        out = torch.empty((T, N, K), dtype=self.ctx.dtype, device=self.ctx.device)
+        w = self.param.detach()
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            w = w.float().contiguous()
+        call("insar_weight_prep", ptr(w), ptr(out), self.ctx.code, T, N, K, st, sn, sk, _lib.stream_ptr())
+        return out
+
+    def fwd(self) -> torch.Tensor:
+        if self._fwd_key != self._key():
+            if self.kind == "conv3":
+                co, ci = self.param.shape[0], self.param.shape[1]
+                self._fwd = self._prep(9, co, ci, 1, ci * 9, 9)
+            else:  # convT (Ci, Co, 2, 2): rows n = q*Co + co
+                ci, co = self.param.shape[0], self.param.shape[1]
+                self._fwd = self._prep(4, co, ci, 1, 4, co * 4)
+            self._fwd_key = self._key()
+        return self._fwd
+
+    def dgrad(self) -> torch.Tensor:
+        if self._dgrad_key != self._key():
+            if self.kind == "conv3":
+                co, ci = self.param.shape[0], self.param.shape[1]
+                self._dgrad = self._prep(9, ci, co, 1, 9, ci * 9)
+            else:
+                ci, co = self.param.shape[0], self.param.shape[1]
+                self._dgrad = self._prep(4, ci, co, 1, co * 4, 4)
+            self._dgrad_key = self._key()
+        return self._dgrad
+
+
+_TAPS3 = [(r - 1, s - 1) for r in range(3) for s in range(3)]
+_TAPS3_DGRAD = [(1 - r, 1 - s) for r in range(3) for s in range(3)]
+_TAPS2 = [(a, b) for a in range(2) for b in range(2)]
+
+
+def _igemm(x: Act, y: Act, w: torch.Tensor, N: int, Ho: int, Wo: int, stride: int, taps, mode: int,
+           bias: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None) -> None:
+    d = InsarIgemm()
+    d.x, d.y = x.desc, y.desc
+    d.w, d.bias, d.stats = ptr(w), ptr(bias), ptr(stats)
+    d.N, d.Ho, d.Wo, d.stride, d.ntaps, d.mode = N, Ho, Wo, stride, len(taps), mode
+    for i, (dy, dx) in enumerate(taps):
+        d.dy[i], d.dx[i] = dy, dx
+    call("insar_igemm", C.byref(d), _lib.stream_ptr())
+
+
+def _wgrad_nsplit(tiles: int, ksteps: int) -> int:
+    n = max(1, min(round(1536 / max(tiles, 1)), max(1, ksteps // 4)))
+    return int(n)
+
+
+class GradSink:
+    """Flat fp32 gradient buffer: one 16-byte-aligned view per parameter, in backward order."""
+
+    def __init__(self, ctx: Ctx, params: List[torch.nn.Parameter]):
+        self.params = list(params)
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += _round_up(p.numel(), 4)
+        self.flats = [torch.zeros(total, dtype=torch.float32, device=ctx.device) for _ in range(2)]
+        self.views = [{id(p): f[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, offs)} for f in self.flats]
+        self.active = 0
+
+    def select(self) -> None:
+        """Pick the flat buffer that no live `.grad` aliases (see UNet backward)."""
+        for which in (0, 1):
+            base, n = self.flats[which].data_ptr(), self.flats[which].numel() * 4
+            if not any(p.grad is not None and base <= p.grad.data_ptr() < base + n for p in self.params):
+                self.active = which
+                return
+        self.active = 0
+
+    def view(self, p: torch.nn.Parameter) -> torch.Tensor:
+        return self.views[self.active][id(p)]
+
+    def flat(self) -> torch.Tensor:
+        return self.flats[self.active]
+
+
+class ConvBN:
+    """conv3x3 (bias) -> BatchNorm2d -> ReLU, the unit DoubleConv is made of (:81-86)."""
+
+    def __init__(self, ctx: Ctx, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, x: Act, name: str):
+        self.ctx, self.conv, self.bn, self.x, self.name = ctx, conv, bn, x, name
+        B, H, W = x.B, x.H, x.W
+        self.cin, self.cout = conv.in_channels, conv.out_channels
+        if x.c_len != self.cin:
+            raise _lib.InsarError(f"{name}: input slice has {x.c_len} channels, conv expects {self.cin}")
+        self.small = self.cin <= 4
+        if not self.small and self.cin % 64:
+            raise _lib.InsarError(f"{name}: in_channels={self.cin} must be <=4 or a multiple of 64 on the HIP path")
+        if self.cout % 64:
+            raise _lib.InsarError(f"{name}: out_channels={self.cout} must be a multiple of 64 on the HIP path")
+        self.M = B * H * W
+        self.y = Act.alloc(B, H, W, self.cout, ctx.dtype, ctx.device)           # raw conv output (no bias)
+        self.stat_rows = B * H if self.small else call("insar_igemm_num_mtiles", self.M)
+        self.stats = ctx.f32(self.stat_rows, 2, self.cout)
+        self.sums = ctx.f32(2, self.cout)
+        self.scale, self.shift = ctx.f32(self.cout), ctx.f32(self.cout)
+        self.mean, self.invstd = ctx.f32(self.cout), ctx.f32(self.cout)
+        self.k1, self.k2 = ctx.f32(self.cout), ctx.f32(self.cout)
+        self.red_part = ctx.f32(B * H, 2, self.cout)
+        self.red = ctx.f32(B, 2, self.cout)
+        self.bwd_ws = ctx.f32(B * (3 * self.cout + max(self.cout // 16, 1)))
+        self.dy = None            # gradient wrt the raw conv output (allocated on first backward)
+        self.w = None if self.small else GemmWeight(ctx, conv.weight, "conv3")
+
+    # ---- forward: y = conv(x); BN statistics; scale/shift ---------------------------------------
+    def forward_conv(self, training: bool) -> None:
+        s = _lib.stream_ptr()
+        if self.small:
+            w = self.conv.weight.detach()
+            call("insar_conv3x3_small_fwd", self.x.ref, ptr(w), self.y.ref, ptr(self.stats) if training else 0, s)
+        else:
+            _igemm(self.x, self.y, self.w.fwd(), self.cout, self.x.H, self.x.W, 1, _TAPS3, 0,
+                   stats=self.stats if training else None)
+        if training:
+            self.ctx.colsum(self.stats, self.sums, 1, self.stat_rows, 2 * self.cout)
+        bn = self.bn
+        d = InsarBnFinalize()
+        d.part, d.count, d.C, d.training = ptr(self.sums), self.M, self.cout, int(training)
+        d.conv_bias = ptr(self.conv.bias.detach()) if self.conv.bias is not None else 0
+        d.gamma, d.beta = ptr(bn.weight.detach()), ptr(bn.bias.detach())
+        d.running_mean, d.running_var = ptr(bn.running_mean), ptr(bn.running_var)
+        d.num_batches_tracked = ptr(bn.num_batches_tracked)
+        d.momentum = bn.momentum if bn.momentum is not None else 0.1
+        d.eps = bn.eps
+        d.scale, d.shift, d.mean, d.invstd = ptr(self.scale), ptr(self.shift), ptr(self.mean), ptr(self.invstd)
+        call("insar_bn_finalize", C.byref(d), s)
+
+    def apply(self, dst: Act, gate: Optional[torch.Tensor]) -> None:
+        call("insar_bn_relu_apply", self.y.ref, ptr(self.scale), ptr(self.shift), ptr(gate), dst.ref, 1,
+             _lib.stream_ptr())
+
+    # ---- backward -------------------------------------------------------------------------------
+    def backward(self, dout: Act, sink: GradSink, training: bool, se: Optional["SEState"], dx: Optional[Act]) -> None:
+        """dout: gradient wrt this unit's output (after ReLU and, if `se`, the SE gate)."""
+        ctx, s = self.ctx, _lib.stream_ptr()
+        B, H, W = self.x.B, self.x.H, self.x.W
+        if self.dy is None:
+            self.dy = Act.alloc(B, H, W, self.cout, ctx.dtype, ctx.device)
+        call("insar_bnrelu_bwd_reduce", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.red_part), 1, s)
+        ctx.colsum(self.red_part, self.red, B, H, 2 * self.cout)
+        d = InsarBnSeBwd()
+        d.B, d.H, d.W, d.C = B, H, W, self.cout
+        d.Cr = se.cr if se else 1
+        d.use_se = 1 if se else 0
+        d.mean, d.invstd = ptr(self.mean), ptr(self.invstd)
+        if se:
+            d.pooled, d.sq, d.hid, d.gate = ptr(se.pooled), ptr(se.sq), ptr(se.hid), ptr(se.gate)
+            d.w1, d.w2 = ptr(se.fc1.weight.detach()), ptr(se.fc2.weight.detach())
+            d.dw1, d.dw2 = ptr(sink.view(se.fc1.weight)), ptr(sink.view(se.fc2.weight))
+            d.coefB = ptr(se.coefB)
+        d.dgamma, d.dbeta = ptr(sink.view(self.bn.weight)), ptr(sink.view(self.bn.bias))
+        d.k1, d.k2 = ptr(self.k1), ptr(self.k2)
+        d.accumulate = 0
+        dbias = ptr(sink.view(self.conv.bias)) if self.conv.bias is not None else 0
+        call("insar_bnse_bwd_coef", C.byref(d), ptr(self.red), ptr(self.scale), ptr(self.shift), ptr(self.bwd_ws),
+             dbias, int(training), s)
+        call("insar_bnrelu_bwd_apply", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.mean),
+             ptr(self.invstd), ptr(se.gate) if se else 0, ptr(se.coefB) if se else 0, ptr(self.k1), ptr(self.k2),
+             self.dy.ref, 1, s)
+        # weight gradient
+        gw = sink.view(self.conv.weight)
+        if self.small:
+            nb = call("insar_conv3x3_small_wgrad_blocks", B, H)
+            cols = self.cout * self.cin * 9
+            part = ctx.wgrad_part(nb * cols)
+            call("insar_conv3x3_small_wgrad", self.x.ref, self.dy.ref, ptr(part), s)
+            ctx.colsum(part, gw, 1, nb, cols)
+        else:
+            _wgrad_conv3(ctx, self.x, self.dy, gw)
+        if dx is not None:
+            if self.small:
+                raise _lib.InsarError(f"{self.name}: input gradient of the direct first-layer conv is not provided")
+            _igemm(self.dy, dx, self.w.dgrad(), self.cin, H, W, 1, _TAPS3_DGRAD, 0)
+
+
+def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
+    B, H, W = x.B, x.H, x.W
+    cin, cout = x.c_len, dy.c_len
+    tabx = ctx.pixel_table(B, H, W, 1, H, W, W + 3)      # taps move on x: tail = first interior pixel
+    tabdy = ctx.pixel_table(B, H, W, 1, H, W, 0)         # tail = zero halo pixel
+    mpad = tabx.numel()
+    tm = 128 if (ctx.code == _lib.BF16 and cin % 128 == 0) else 64
+    tn = 128 if (ctx.code == _lib.BF16 and cout % 128 == 0) else 64
+    tiles = 9 * (cin // tm) * (cout // tn)
+    nsplit = _wgrad_nsplit(tiles, mpad // WG_BKP)
+    part = ctx.wgrad_part(nsplit * 9 * cout * cin)
+    d = InsarWgrad()
+    d.x, d.dy = x.desc, dy.desc
+    d.tabx, d.tabdy, d.part = ptr(tabx), ptr(tabdy), ptr(part)
+    d.Mpad, d.nsplit, d.ntaps = mpad, nsplit, 9
+    for i, (ty, tx) in enumerate(_TAPS3):
+        d.offx[i] = ty * (W + 2) + tx
+        d.offdy[i] = 0
+    s = _lib.stream_ptr()
+    call("insar_wgrad", C.byref(d), s)
+    call("insar_wgrad_reduce", ptr(part), ptr(grad), nsplit, 9, cout, cin, 0, 0, s)
+
+
+class SEState:
+    """Buffers of one SELayer (:45-72) attached to the second ConvBN of a DoubleConv."""
+
+    def __init__(self, ctx: Ctx, se_module, B: int, H: int, Cn: int):
+        self.fc1, self.fc2 = se_module.fc[0], se_module.fc[2]
+        self.cr = self.fc1.out_features
+        self.part = ctx.f32(B * H, 2, Cn)
+        self.pooled = ctx.f32(B, 2, Cn)
+        self.sq, self.gate, self.coefB = ctx.f32(B, Cn), ctx.f32(B, Cn), ctx.f32(B, Cn)
+        self.hid = ctx.f32(B, self.cr)
+
+
+class DoubleConvPlan:
+    """[conv3x3 -> BN -> ReLU] x 2 (+ SELayer) = DoubleConv.forward (:75-97)."""
+
+    def __init__(self, ctx: Ctx, mod, x: Act, out: Act, name: str):
+        self.ctx, self.mod, self.x, self.out, self.name = ctx, mod, x, out, name
+        seq = mod.double_conv
+        self.u1 = ConvBN(ctx, seq[0], seq[1], x, name + ".0")
+        self.z1 = Act.alloc(x.B, x.H, x.W, self.u1.cout, ctx.dtype, ctx.device)
+        self.u2 = ConvBN(ctx, seq[3], seq[4], self.z1, name + ".3")
+        self.se = SEState(ctx, seq[6], x.B, x.H, self.u2.cout) if len(seq) > 6 else None
+        if out.c_len != self.u2.cout:
+            raise _lib.InsarError(f"{name}: output slice has {out.c_len} channels, expected {self.u2.cout}")
+        self.dz1 = None
+
+    def params(self) -> List[torch.nn.Parameter]:
+        seq = self.mod.double_conv
+        ps = [seq[0].weight, seq[0].bias, seq[1].weight, seq[1].bias,
+              seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias]
+        if self.se:
+            ps += [self.se.fc1.weight, self.se.fc2.weight]
+        return ps
+
+    def forward(self, training: bool) -> None:
+        s = _lib.stream_ptr()
+        self.u1.forward_conv(training)
+        self.u1.apply(self.z1, None)
+        self.u2.forward_conv(training)
+        if self.se:
+            se, u2 = self.se, self.u2
+            call("insar_se_squeeze", u2.y.ref, ptr(u2.scale), ptr(u2.shift), ptr(se.part), 1, s)
+            self.ctx.colsum(se.part, se.pooled, self.x.B, self.x.H, 2 * u2.cout)
+            d = InsarSeFwd()
+            d.pooled, d.B, d.H, d.W, d.C, d.Cr = ptr(se.pooled), self.x.B, self.x.H, self.x.W, u2.cout, se.cr
+            d.scale, d.shift = ptr(u2.scale), ptr(u2.shift)
+            d.w1, d.w2 = ptr(se.fc1.weight.detach()), ptr(se.fc2.weight.detach())
+            d.sq, d.hid, d.gate = ptr(se.sq), ptr(se.hid), ptr(se.gate)
+            call("insar_se_excite", C.byref(d), s)
+            u2.apply(self.out, se.gate)
+        else:
+            self.u2.apply(self.out, None)
+
+    def backward(self, dout: Act, sink: GradSink, training: bool, dx: Optional[Act]) -> None:
+        if self.dz1 is None:
+            self.dz1 = Act.alloc(self.x.B, self.x.H, self.x.W, self.u1.cout, self.ctx.dtype, self.ctx.device)
+        self.u2.backward(dout, sink, training, self.se, self.dz1)
+        self.u1.backward(self.dz1, sink, training, None, dx)
+
+
+class UpPlan:
+    """ConvTranspose2d(k=2, s=2) (:112,115,118,121) writing the upper half of a concat buffer."""
+
+    def __init__(self, ctx: Ctx, mod: torch.nn.ConvTranspose2d, x: Act, out: Act, name: str):
+        self.ctx, self.mod, self.x, self.out, self.name = ctx, mod, x, out, name
+        self.cin, self.cout = mod.in_channels, mod.out_channels
+        if self.cin % 64 or self.cout % 64:
+            raise _lib.InsarError(f"{name}: channels must be multiples of 64 on the HIP path")
+        self.w = GemmWeight(ctx, mod.weight, "convT")
+        self.bias_part = ctx.f32(out.B * out.H, 2, self.cout)
+
+    def params(self):
+        return [self.mod.weight, self.mod.bias]
+
+    def forward(self) -> None:
+        _igemm(self.x, self.out, self.w.fwd(), 4 * self.cout, self.x.H, self.x.W, 1, [(0, 0)], 1,
+               bias=self.mod.bias.detach() if self.mod.bias is not None else None)
+
+    def backward(self, dout: Act, sink: GradSink, dx: Optional[Act]) -> None:
+        """dout: gradient slice wrt this layer's output (upper half of the dcat buffer)."""
+        ctx, s = self.ctx, _lib.stream_ptr()
+        x, B, h, w = self.x, self.x.B, self.x.H, self.x.W
+        if self.mod.bias is not None:     # dbias = sum over pixels of dout (mask-free row reduction)
+            call("insar_bnrelu_bwd_reduce", dout.ref, dout.ref, ptr(ctx.const(0.0, self.cout)),
+                 ptr(ctx.const(1.0, self.cout)), ptr(self.bias_part), 0, s)
+            tmp = ctx.f32(2, self.cout)
+            ctx.colsum(self.bias_part, tmp, 1, dout.B * dout.H, 2 * self.cout)
+            sink.view(self.mod.bias).copy_(tmp[0])
+        tabx = ctx.pixel_table(B, h, w, 1, h, w, 0)
+        tabdy = ctx.pixel_table(B, h, w, 2, dout.H, dout.W, 0)
+        mpad = tabx.numel()
+        tm = 128 if (ctx.code == _lib.BF16 and self.cin % 128 == 0) else 64
+        tn = 128 if (ctx.code == _lib.BF16 and self.cout % 128 == 0) else 64
+        tiles = 4 * (self.cin // tm) * (self.cout // tn)
+        nsplit = _wgrad_nsplit(tiles, mpad // WG_BKP)
+        part = ctx.wgrad_part(nsplit * 4 * self.cout * self.cin)
+        d = InsarWgrad()
+        d.x, d.dy = x.desc, dout.desc
+        d.tabx, d.tabdy, d.part = ptr(tabx), ptr(tabdy), ptr(part)
+        d.Mpad, d.nsplit, d.ntaps = mpad, nsplit, 4
+        for i, (a, b) in enumerate(_TAPS2):
+            d.offx[i] = 0
+            d.offdy[i] = a * (dout.W + 2) + b
+        call("insar_wgrad", C.byref(d), s)
+        call("insar_wgrad_reduce", ptr(part), ptr(sink.view(self.mod.weight)), nsplit, 4, self.cout, self.cin, 1, 0, s)
+        if dx is not None:
+            _igemm(dout, dx, self.w.dgrad(), self.cin, h, w, 2, _TAPS2, 0)
+
+
+class OutConvPlan:
+    """outc = Conv2d(64, num_classes, 1) (:125,162): NHWC activations -> NCHW fp32 logits."""
+
+    def __init__(self, ctx: Ctx, mod: torch.nn.Conv2d, x: Act, name: str = "outc"):
+        self.ctx, self.mod, self.x = ctx, mod, x
+        self.K, self.cin = mod.out_channels, mod.in_channels
+        self.nb = call("insar_conv1x1_out_bwd_blocks", x.B, x.H)
+        self.cols = self.K * self.cin + self.K
+        self.part = ctx.f32(self.nb, self.cols)
+        self.folded = ctx.f32(self.cols)
+
+    def params(self):
+        return [self.mod.weight, self.mod.bias]
+
+    def forward(self) -> torch.Tensor:
+        x = self.x
+        logits = torch.empty((x.B, self.K, x.H, x.W), dtype=torch.float32, device=self.ctx.device)
+        call("insar_conv1x1_out_fwd", x.ref, ptr(self.mod.weight.detach()),
+             ptr(self.mod.bias.detach()) if self.mod.bias is not None else 0, ptr(logits), self.K, _lib.stream_ptr())
+        return logits
+
+    def backward(self, dlogits: torch.Tensor, sink: GradSink, dx: Act) -> None:
+        call("insar_conv1x1_out_bwd", self.x.ref, ptr(self.mod.weight.detach()), ptr(dlogits), self.K, dx.ref,
+             ptr(self.part), _lib.stream_ptr())
+        self.ctx.colsum(self.part, self.folded, 1, self.nb, self.cols)
+        kc = self.K * self.cin
+        sink.view(self.mod.weight).view(-1).copy_(self.folded[:kc])
+        if self.mod.bias is not None:
+            sink.view(self.mod.bias).copy_(self.folded[kc:])
+
+
+def pack_input(x: torch.Tensor, dst: Act) -> None:
+    """NCHW tensor at the nn.Module boundary -> padded NHWC slice."""
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        x = x.float().contiguous()
+    call("insar_pack_nchw", ptr(x), dst.ref, _lib.stream_ptr())
+
+
+def unpack_output(src: Act) -> torch.Tensor:
+    out = torch.empty((src.B, src.c_len, src.H, src.W), dtype=torch.float32, device=src.buf.device)
+    call("insar_unpack_nchw", src.ref, ptr(out), _lib.stream_ptr())
+    return out
+
+
+class UNetPlan:
+    """All buffers + the launch sequence of UNet.forward / backward for one input geometry."""
+
+    def __init__(self, net, B: int, H: int, W: int, dtype: torch.dtype, device: torch.device):
+        if H % 16 or W % 16:
+            raise _lib.InsarError(
+                f"H={H}, W={W}: the HIP path covers tile sizes that are multiples of 16 (the reference's "
+                "bilinear-resize fallback, Unet-ChannalAttention.py:138-139, is not part of the hot path)")
+        self.net, self.B, self.H, self.W = net, B, H, W
+        ctx = self.ctx = Ctx(device, dtype)
+        widths = [net.inc.double_conv[0].out_channels]
+        downs = [net.down1, net.down2, net.down3, net.down4]
+        for d in downs:
+            widths.append(d[1].double_conv[0].out_channels)
+        self.widths = widths
+        cin = net.inc.double_conv[0].in_channels
+        hs = [H >> l for l in range(5)]
+        ws = [W >> l for l in range(5)]
+        A = lambda l, c: Act.alloc(B, hs[l], ws[l], c, dtype, device)
+        self.xin = A(0, cin)
+        self.cat = [A(l, 2 * widths[l]) for l in range(4)]
+        self.x5 = A(4, widths[4])
+        self.pooled = [A(l + 1, widths[l]) for l in range(4)]
+        self.dec = [A(l, widths[l]) for l in range(4)]
+        # gradients
+        self.dcat = [A(l, 2 * widths[l]) for l in range(4)]
+        self.dx5 = A(4, widths[4])
+        self.dpooled = [A(l + 1, widths[l]) for l in range(4)]
+        self.ddec = [A(l, widths[l]) for l in range(4)]
+
+        self.enc: List[DoubleConvPlan] = []
+        enc_mods = [net.inc] + [d[1] for d in downs]
+        enc_names = ["inc"] + [f"down{i}.1" for i in range(1, 5)]
+        for l in range(5):
+            xin = self.xin if l == 0 else self.pooled[l - 1]
+            out = self.cat[l].slice(0, widths[l]) if l < 4 else self.x5
+            self.enc.append(DoubleConvPlan(ctx, enc_mods[l], xin, out, enc_names[l]))
+        ups = [net.up1, net.up2, net.up3, net.up4]
+        convs = [net.conv1, net.conv2, net.conv3, net.conv4]
+        self.up: List[UpPlan] = []
+        self.dconv: List[DoubleConvPlan] = []
+        for i in range(4):              # decoder stage i+1 works at level l = 3 - i
+            l = 3 - i
+            src = self.x5 if i == 0 else self.dec[l + 1]
+            self.up.append(UpPlan(ctx, ups[i], src, self.cat[l].slice(widths[l], widths[l]), f"up{i + 1}"))
+            self.dconv.append(DoubleConvPlan(ctx, convs[i], self.cat[l], self.dec[l], f"conv{i + 1}"))
+        self.outc = OutConvPlan(ctx, net.outc, self.dec[0])
+        # parameters in the order their gradients complete during backward
+        order: List[torch.nn.Parameter] = []
+        order += self.outc.params()
+        for i in (3, 2, 1, 0):
+            order += self.dconv[i].params() + self.up[i].params()
+        for l in (4, 3, 2, 1, 0):
+            order += self.enc[l].params()
+        self.grad_params = order
+        self.sink = GradSink(ctx, order)
+        self.busy = False
+        self.training = True
+
+    # ---- forward ----------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, training: bool) -> torch.Tensor:
+        s = _lib.stream_ptr
+        self.training = training
+        pack_input(x, self.xin)
+        for l in range(5):
+            self.enc[l].forward(training)
+            if l < 4:
+                call("insar_maxpool2_fwd", self.enc[l].out.ref, self.pooled[l].ref, s())
+        for i in range(4):
+            self.up[i].forward()
+            self.dconv[i].forward(training)
+        return self.outc.forward()
+
+    # ---- backward ---------------------------------------------------------------------------------
+    def backward(self, dlogits: torch.Tensor, on_bucket=None) -> List[torch.Tensor]:
+        s = _lib.stream_ptr
+        if dlogits.dtype != torch.float32 or not dlogits.is_contiguous():
+            dlogits = dlogits.float().contiguous()
+        sink, training, w = self.sink, self.training, self.widths
+        sink.select()
+        self.outc.backward(dlogits, sink, self.ddec[0])
+        for i in (3, 2, 1, 0):
+            l = 3 - i
+            self.dconv[i].backward(self.ddec[l], sink, training, self.dcat[l])
+            dsrc = self.dx5 if i == 0 else self.ddec[l + 1]
+            self.up[i].backward(self.dcat[l].slice(w[l], w[l]), sink, dsrc)
+            if on_bucket is not None:
+                on_bucket(self, ("dec", i))
+        for l in (4, 3, 2, 1, 0):
+            dout = self.dx5 if l == 4 else self.dcat[l].slice(0, w[l])
+            self.enc[l].backward(dout, sink, training, self.dpooled[l - 1] if l > 0 else None)
+            if l > 0:
+                call("insar_maxpool2_bwd", self.enc[l - 1].out.ref, self.dpooled[l - 1].ref,
+                     self.dcat[l - 1].slice(0, w[l - 1]).ref, 1, s())
+            if on_bucket is not None:
+                on_bucket(self, ("enc", l))
+        return [sink.view(p) for p in self.grad_params]
