@@ -140,6 +140,34 @@ class GemmWeight:
         return self._dgrad
 
 
+class KernelTimer:
+    """Optional HIP-event timing of the GEMM-class launches (bench.py's roofline leg). Events are
+    recorded on torch's current stream, which is the stream the kernels are launched on."""
+
+    def __init__(self):
+        self.records: Dict[str, list] = {}
+
+    def run(self, tag: str, flops: float, fn) -> None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.records.setdefault(tag, []).append((e0, e1, flops))
+
+    def summary(self) -> Dict[str, dict]:
+        torch.cuda.synchronize()
+        out = {}
+        for tag, recs in self.records.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+            fl = sum(f for _, _, f in recs)
+            out[tag] = {"launches": len(recs), "ms": ms, "flops": fl,
+                        "avg_us": 1e3 * ms / max(len(recs), 1), "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
+        return out
+
+
+PROFILER: Optional[KernelTimer] = None
+
+
 _TAPS3 = [(r - 1, s - 1) for r in range(3) for s in range(3)]
 _TAPS3_DGRAD = [(1 - r, 1 - s) for r in range(3) for s in range(3)]
 _TAPS2 = [(a, b) for a in range(2) for b in range(2)]
@@ -153,7 +181,20 @@ def _igemm(x: Act, y: Act, w: torch.Tensor, N: int, Ho: int, Wo: int, stride: in
     d.N, d.Ho, d.Wo, d.stride, d.ntaps, d.mode = N, Ho, Wo, stride, len(taps), mode
     for i, (dy, dx) in enumerate(taps):
         d.dy[i], d.dx[i] = dy, dx
+    if PROFILER is not None:
+        flops = 2.0 * x.B * Ho * Wo * N * x.c_len * len(taps)
+        tag = ("igemm_f32" if x.code == _lib.F32 else "igemm_bf16") + ("_bn128" if N % 128 == 0 else "_bn64")
+        PROFILER.run(tag, flops, lambda: call("insar_igemm", C.byref(d), _lib.stream_ptr()))
+        return
     call("insar_igemm", C.byref(d), _lib.stream_ptr())
+
+
+def _launch_wgrad(d: InsarWgrad, M: int, cin: int, cout: int, ntaps: int, code: int) -> None:
+    if PROFILER is not None:
+        tag = "wgrad_f32" if code == _lib.F32 else "wgrad_bf16"
+        PROFILER.run(tag, 2.0 * M * cin * cout * ntaps, lambda: call("insar_wgrad", C.byref(d), _lib.stream_ptr()))
+        return
+    call("insar_wgrad", C.byref(d), _lib.stream_ptr())
 
 
 def _wgrad_nsplit(tiles: int, ksteps: int) -> int:
@@ -308,7 +349,7 @@ def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
         d.offx[i] = ty * (W + 2) + tx
         d.offdy[i] = 0
     s = _lib.stream_ptr()
-    call("insar_wgrad", C.byref(d), s)
+    _launch_wgrad(d, B * H * W, cin, cout, 9, ctx.code)
     call("insar_wgrad_reduce", ptr(part), ptr(grad), nsplit, 9, cout, cin, 0, 0, s)
 
 
@@ -415,7 +456,7 @@ class UpPlan:
         for i, (a, b) in enumerate(_TAPS2):
             d.offx[i] = 0
             d.offdy[i] = a * (dout.W + 2) + b
-        call("insar_wgrad", C.byref(d), s)
+        _launch_wgrad(d, B * h * w, self.cin, self.cout, 4, ctx.code)
         call("insar_wgrad_reduce", ptr(part), ptr(sink.view(self.mod.weight)), nsplit, 4, self.cout, self.cin, 1, 0, s)
         if dx is not None:
             _igemm(dout, dx, self.w.dgrad(), self.cin, h, w, 2, _TAPS2, 0)
@@ -521,8 +562,25 @@ class UNetPlan:
             order += self.enc[l].params()
         self.grad_params = order
         self.sink = GradSink(ctx, order)
+        # flat-buffer offsets at which each backward stage's gradients are complete (for DP buckets)
+        stage_sizes = []
+        first = self.outc.params() + self.dconv[3].params() + self.up[3].params()
+        stage_sizes.append(sum(_round_up(p.numel(), 4) for p in first))
+        for i in (2, 1, 0):
+            stage_sizes.append(sum(_round_up(p.numel(), 4) for p in self.dconv[i].params() + self.up[i].params()))
+        for l in (4, 3, 2, 1, 0):
+            stage_sizes.append(sum(_round_up(p.numel(), 4) for p in self.enc[l].params()))
+        self.stage_sizes = stage_sizes
+        self.stage_ends = [sum(stage_sizes[:i + 1]) for i in range(len(stage_sizes))]
+        self._closes = {}
         self.busy = False
         self.training = True
+
+    def bucket_closes(self, min_elems: int):
+        if min_elems not in self._closes:
+            from .parallel import plan_buckets
+            self._closes[min_elems] = set(plan_buckets(self.stage_sizes, min_elems))
+        return self._closes[min_elems]
 
     # ---- forward ----------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, training: bool) -> torch.Tensor:

@@ -175,7 +175,7 @@ def adam_update(params: List[torch.Tensor], grads: List[torch.Tensor], state: Di
             p.addcdiv_(st["m"], denom, value=-lr / bc1)
 
 
-def train_step(sd, opt_state, x, target, use_se=True, lr=1e-4) -> Tuple[float, torch.Tensor]:
+def train_step(sd, opt_state, x, target, use_se=True, lr=1e-4, dice_weight: float = 0.0) -> Tuple[float, torch.Tensor]:
     """One iteration of the reference's hot loop, Unet-ChannalAttention.py:342-346:
     zero_grad -> forward -> CE -> backward -> Adam.step. Mutates `sd` / `opt_state`."""
     names = [k for k in sd if is_param(k)]
@@ -187,6 +187,8 @@ def train_step(sd, opt_state, x, target, use_se=True, lr=1e-4) -> Tuple[float, t
         leaves.append(leaf)
     logits = unet_forward(work, x, use_se=use_se, training=True)
     loss = cross_entropy(logits, target)
+    if dice_weight:
+        loss = loss + dice_weight * soft_dice_loss(logits, target)
     grads = torch.autograd.grad(loss, leaves)
     for k in sd:                                      # BN buffers were updated in `work`
         if not is_param(k):
