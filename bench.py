@@ -36,7 +36,11 @@ def cpu_baseline(batch: int = 2, size: int = 256):
     from insar_unet_ca_amd.data import make_batch
     from oracle import unet_ca_oracle as orc
 
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))           # the GPU box gives one GPU a 16-core share
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     import insar_unet_ca_amd as iu
@@ -131,7 +135,7 @@ def main() -> int:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank == 0:
         tiles = args.batch * world * args.steps

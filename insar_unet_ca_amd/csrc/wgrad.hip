@@ -264,19 +264,35 @@ extern "C" int insar_wgrad(const InsarWgrad* d, void* stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fold the split-K partial slabs and re-lay [tap][co][ci] out to the torch parameter layout.
+// One block owns (co, 128 consecutive ci): slab reads are coalesced along ci, the tile is
+// transposed through LDS ([ci][tap], odd pitch), and the parameter-layout writes are
+// contiguous (Conv2d: 128*ntaps consecutive floats).
+// ---------------------------------------------------------------------------------------------
+#define WR_CIT 128
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ grad, int nsplit, int ntaps,
                                     int Co, int Ci, int layout, int accumulate) {
+  __shared__ float t[WR_CIT * 12];
+  const int co = blockIdx.x, ci0 = blockIdx.y * WR_CIT;
+  const int nci = (Ci - ci0) < WR_CIT ? (Ci - ci0) : WR_CIT;
   const long long total = (long long)Co * Ci;
   const long long slab = total * ntaps;
-  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    const int co = (int)(e / Ci), ci = (int)(e - (long long)co * Ci);
-    const long long o = layout == 0 ? e : ((long long)ci * Co + co);
-    for (int tap = 0; tap < ntaps; ++tap) {
-      float s = 0.f;
-      const float* p = part + (long long)tap * total + e;
-      for (int sp = 0; sp < nsplit; ++sp) s += p[(long long)sp * slab];
-      float* g = grad + o * ntaps + tap;
-      *g = accumulate ? *g + s : s;
+  for (int idx = threadIdx.x; idx < ntaps * nci; idx += blockDim.x) {
+    const int tap = idx / nci, c = idx - tap * nci;
+    const float* p = part + (long long)tap * total + (long long)co * Ci + ci0 + c;
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += p[(long long)sp * slab];
+    t[c * ntaps + tap] = s;
+  }
+  __syncthreads();
+  if (layout == 0) {
+    float* g = grad + ((long long)co * Ci + ci0) * ntaps;
+    for (int j = threadIdx.x; j < nci * ntaps; j += blockDim.x) g[j] = accumulate ? g[j] + t[j] : t[j];
+  } else {
+    for (int j = threadIdx.x; j < nci * ntaps; j += blockDim.x) {
+      const int c = j / ntaps, tap = j - c * ntaps;
+      float* g = grad + ((long long)(ci0 + c) * Co + co) * ntaps + tap;
+      *g = accumulate ? *g + t[j] : t[j];
     }
   }
 }
@@ -285,9 +301,10 @@ extern "C" int insar_wgrad_reduce(const float* part, float* grad, int32_t nsplit
                                   int32_t layout, int32_t accumulate, void* stream) {
   if (!part || !grad) INSAR_FAIL(INSAR_E_ARG, "insar_wgrad_reduce: null pointer");
   if (layout != 0 && layout != 1) INSAR_FAIL(INSAR_E_ARG, "insar_wgrad_reduce: layout");
-  const long long total = (long long)Co * Ci;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(insar_grid_cap((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     part, grad, nsplit, ntaps, Co, Ci, layout, accumulate);
+  if (ntaps < 1 || ntaps > 12 || Co < 1 || Ci < 1 || nsplit < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_wgrad_reduce: bad shape");
+  dim3 grid(Co, (Ci + WR_CIT - 1) / WR_CIT);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, part, grad, nsplit, ntaps, Co, Ci,
+                     layout, accumulate);
   INSAR_CHECK_LAUNCH("insar_wgrad_reduce");
   return INSAR_OK;
 }
