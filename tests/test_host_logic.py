@@ -1,0 +1,151 @@
+"""CPU-only: the host side of the product (module surface, plans, optimizer state, data, DP
+bucketing) without running any kernel."""
+import collections
+
+import numpy as np
+import pytest
+import torch
+
+import insar_unet_ca_amd as iu
+from insar_unet_ca_amd import _lib, engine, modules
+from insar_unet_ca_amd.data import SyntheticTiles, make_batch, make_tile
+from insar_unet_ca_amd.parallel import plan_buckets
+from oracle import unet_ca_oracle as orc
+
+
+def test_state_dict_contract_matches_reference(golden):
+    g3 = golden("g3_unet")
+    net = iu.UNet(in_channels=2, num_classes=2, use_se=True)
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g3["state_dict_keys"]]
+    assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in g3["state_dict_shapes"]]
+    assert sum(p.numel() for p in net.parameters()) == 31261122
+    # Unet.py-equivalent (no attention) and the reference default in_channels=1
+    assert list(iu.UNet(1, 2, False).state_dict().keys()) == list(orc.state_dict_template(1, 2, False).keys())
+
+
+def test_state_dict_roundtrip_with_oracle_template():
+    from oracle import closed_form as cf
+    net = iu.UNet(2, 2, True)
+    filled = cf.fill_state_dict(orc.state_dict_template(2, 2, True))
+    net.load_state_dict(filled)                       # strict: same keys + shapes
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, filled[k])
+
+
+def test_default_init_consumes_rng_like_the_reference():
+    """Same module construction order => same torch default init under the same seed."""
+    torch.manual_seed(123)
+    a = iu.UNet(2, 2, True).state_dict()
+    torch.manual_seed(123)
+    b = iu.UNet(2, 2, True).state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    w = a["inc.double_conv.0.weight"]
+    bound = 1.0 / np.sqrt(2 * 9)                      # kaiming_uniform(a=sqrt(5)) bound = 1/sqrt(fan_in)
+    assert float(w.abs().max()) <= bound + 1e-6
+
+
+def test_no_cpu_fallback():
+    net = iu.UNet(2, 2, True)
+    with pytest.raises(iu.InsarError, match="no CPU fallback"):
+        net(torch.zeros(1, 2, 16, 16))
+    with pytest.raises(iu.InsarError, match="no CPU fallback"):
+        iu.DoubleConv(64, 64)(torch.zeros(1, 64, 16, 16))
+    with pytest.raises(iu.InsarError, match="no CPU fallback"):
+        iu.CrossEntropyLoss(ignore_index=255)(torch.zeros(1, 2, 4, 4), torch.zeros(1, 4, 4, dtype=torch.long))
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.ones(4)
+    with pytest.raises(iu.InsarError, match="no CPU fallback"):
+        iu.Adam([p]).step()
+
+
+def test_unsupported_configurations_fail_loudly():
+    with pytest.raises(iu.InsarError):
+        iu.CrossEntropyLoss(reduction="sum")
+    with pytest.raises(iu.InsarError):
+        iu.Adam([torch.nn.Parameter(torch.zeros(1))], weight_decay=0.1)
+
+
+@pytest.fixture
+def mocked_abi(monkeypatch):
+    calls = []
+
+    def fake_call(name, *a):
+        calls.append(name)
+        if name == "insar_igemm_num_mtiles":
+            return (a[0] + 127) // 128
+        if name == "insar_conv3x3_small_wgrad_blocks":
+            return min(a[0] * a[1], 512)
+        if name == "insar_conv1x1_out_bwd_blocks":
+            return min(a[0] * a[1], 1024)
+        if name == "insar_ce_blocks":
+            return min((a[0] + 255) // 256, 1024)
+        return 0
+
+    for m in (_lib, engine, modules):
+        monkeypatch.setattr(m, "call", fake_call, raising=False)
+    monkeypatch.setattr(_lib, "stream_ptr", lambda: 0)
+    monkeypatch.setattr(modules, "_require_device", lambda x, who: None)
+    return calls
+
+
+def test_plan_launch_sequence(mocked_abi):
+    """The plan issues the expected number of launches per kernel family for one training step."""
+    net = iu.UNet(2, 2, True)
+    x = torch.zeros(2, 2, 32, 32)
+    y = net(x)
+    assert y.shape == (2, 2, 32, 32) and y.dtype == torch.float32
+    y.sum().backward()
+    c = collections.Counter(mocked_abi)
+    assert c["insar_igemm"] == 17 + 4 + 17 + 4          # conv fwd (18-1 direct) + convT fwd + dgrads
+    assert c["insar_wgrad"] == 17 + 4
+    assert c["insar_conv3x3_small_fwd"] == 1 and c["insar_conv3x3_small_wgrad"] == 1
+    assert c["insar_bn_finalize"] == 18 and c["insar_se_excite"] == 9
+    assert c["insar_maxpool2_fwd"] == 4 and c["insar_maxpool2_bwd"] == 4
+    assert all(p.grad is not None and p.grad.shape == p.shape for p in net.parameters())
+    # gradients alias the plan's flat buffer (no per-step clone) and the next backward must not clobber them
+    plan = net._plan(x)
+    assert net.outc.weight.grad.data_ptr() == plan.sink.view(net.outc.weight).data_ptr()
+    first = plan.sink.active
+    net(x).sum().backward()
+    assert plan.sink.active != first                    # live .grad aliases buffer 0 -> buffer 1 is used
+
+
+def test_plan_rejects_shapes_outside_the_hot_path(mocked_abi):
+    net = iu.UNet(2, 2, True)
+    with pytest.raises(iu.InsarError, match="multiples of 16"):
+        net(torch.zeros(1, 2, 100, 100))
+    with pytest.raises(iu.InsarError, match="input channels"):
+        net(torch.zeros(1, 3, 32, 32))
+
+
+def test_bucket_planning():
+    sizes = [10, 10, 100, 5, 5, 200, 1]
+    assert plan_buckets(sizes, 50) == [2, 5, 6]
+    assert plan_buckets(sizes, 10 ** 9) == [6]
+    assert plan_buckets(sizes, 1) == list(range(7))
+
+
+def test_synthetic_tiles_are_deterministic_and_in_range():
+    a, la = make_tile(1234, 64)
+    b, lb = make_tile(1234, 64)
+    assert np.array_equal(a, b) and np.array_equal(la, lb)
+    assert a.shape == (2, 64, 64) and a.dtype == np.float32 and la.dtype == np.int64
+    assert -1.0 <= a.min() and a.max() <= 1.0
+    np.testing.assert_allclose(a[0] ** 2 + a[1] ** 2, 1.0, atol=1e-5)   # (cos, sin) of the wrapped phase
+    assert set(np.unique(la)) <= {0, 1}
+    x, y = make_batch(0, 3, 32)
+    assert x.shape == (3, 2, 32, 32) and y.shape == (3, 32, 32)
+    ds = SyntheticTiles(5, 32)
+    assert len(ds) == 5 and torch.equal(ds[2][0], make_batch(2, 1, 32)[0][0])
+    frac = np.mean([make_tile(1000 + i, 256)[1].mean() for i in range(8)])
+    assert 0.005 < frac < 0.12
+
+
+def test_adam_state_dict_is_torch_compatible():
+    p = [torch.nn.Parameter(torch.ones(3))]
+    ours, ref = iu.Adam(p, lr=1e-4), torch.optim.Adam(p, lr=1e-4)
+    ko = {k for k in ours.state_dict()["param_groups"][0]}
+    kr = {k for k in ref.state_dict()["param_groups"][0]}
+    assert ko == kr
+    ref.load_state_dict(ours.state_dict())

@@ -1,0 +1,543 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the drop-in module
+surface and the C ABI, against (a) the golden vectors generated from the reference itself
+(tests/golden, see oracle/gen_golden.py), (b) the CPU oracle on the same seeded inputs, and (c)
+size-independent properties at the full BASELINE configuration.
+
+Tolerances
+  forward, fp32 : max-rel <= 1e-3 (north_star); observed ~1e-5.
+  backward, fp32: two fp32 implementations disagree on the ReLU mask of any pre-activation that sits
+                  within rounding of 0, which changes that element's gradient by O(1). So:
+                  kernel-level gradient tests (no ReLU) are tight (<= 2e-5 max-rel against float64 on
+                  the kernel's own operands); block/network gradient tests use rel-L2 with a floor
+                  derived from torch's own fp32-vs-fp64 disagreement on the same fixture.
+  bf16          : calibrated against torch's own bf16 on the same fixture (max-rel 0.08-0.10,
+                  98.3-98.7 % argmax agreement, measured in-container): gates 0.15 / 97.5 %.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import closed_form as cf
+from oracle import unet_ca_oracle as orc
+from tests.helpers import check_summary, max_rel, to_np
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1e-3          # north_star
+KERNEL_TOL = 2e-5
+BF16_FWD_TOL = 0.15
+BF16_ARGMAX = 0.975
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm device")
+    from insar_unet_ca_amd import _lib
+    _lib.load()                      # fail loudly if the extension is missing
+    return torch.device("cuda:0")
+
+
+def rel_l2(a, b):
+    a, b = to_np(a), to_np(b)
+    den = np.linalg.norm(b)
+    return float(np.linalg.norm(a - b) / (den if den > 0 else 1.0))
+
+
+def _filled(mod):
+    mod.load_state_dict(cf.fill_state_dict(mod.state_dict()))
+    return mod
+
+
+def _act_from(x, dtype, dev):
+    from insar_unet_ca_amd import engine
+    b, c, h, w = x.shape
+    a = engine.Act.alloc(b, h, w, c, dtype, dev)
+    engine.pack_input(x.to(dev), a)
+    return a
+
+
+def _halo_abs(a):
+    t = a.buf.float().clone()
+    t[:, 1:-1, 1:-1] = 0
+    return float(t.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------
+# kernel level: implicit GEMM forward / dgrad / wgrad, transposed conv — tight, no ReLU involved
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,shape", [
+    (64, 128, (2, 64, 16, 16)),
+    (128, 64, (1, 128, 8, 24)),      # 192 pixels: partial M tile
+    (256, 256, (2, 256, 8, 8)),
+    (64, 64, (3, 64, 4, 4)),         # 48 pixels: M smaller than one tile
+])
+def test_igemm_family_against_float64(dev, dtype, cin, cout, shape):
+    from insar_unet_ca_amd import engine
+    from insar_unet_ca_amd._lib import call
+    ctx = engine.Ctx(dev, dtype)
+    b, _, h, w = shape
+    xa = _act_from(cf.make_input(shape), dtype, dev)
+    ya = engine.Act.alloc(b, h, w, cout, dtype, dev)
+    p = torch.nn.Parameter(cf.fill_tensor("weight", (cout, cin, 3, 3), 11).to(dev))
+    gw = engine.GemmWeight(ctx, p, "conv3")
+    stats = torch.zeros(call("insar_igemm_num_mtiles", b * h * w), 2, cout, device=dev)
+    engine._igemm(xa, ya, gw.fwd(), cout, h, w, 1, engine._TAPS3, 0, stats=stats)
+    xr = xa.nchw().cpu().double()                         # operands exactly as the kernel saw them
+    wr = gw.fwd().float().cpu().reshape(3, 3, cout, cin).permute(2, 3, 0, 1).double()
+    ref = F.conv2d(xr, wr, padding=1)
+    tol = KERNEL_TOL if dtype == torch.float32 else 6e-3   # bf16: only the output rounding remains
+    assert max_rel(ya.nchw(), ref) <= tol
+    assert _halo_abs(ya) == 0.0
+    got = ya.nchw().double().cpu()
+    assert max_rel(stats.sum(0)[0], got.sum((0, 2, 3))) <= 1e-5
+    assert max_rel(stats.sum(0)[1], (got ** 2).sum((0, 2, 3))) <= 1e-5
+    ga = _act_from(cf.make_grad((b, cout, h, w)), dtype, dev)
+    dxa = engine.Act.alloc(b, h, w, cin, dtype, dev)
+    engine._igemm(ga, dxa, gw.dgrad(), cin, h, w, 1, engine._TAPS3_DGRAD, 0)
+    gr = ga.nchw().cpu().double()
+    assert max_rel(dxa.nchw(), F.conv_transpose2d(gr, wr, padding=1)) <= tol
+    gwt = torch.zeros(cout, cin, 3, 3, device=dev)
+    engine._wgrad_conv3(ctx, xa, ga, gwt)
+    wv = wr.clone().requires_grad_(True)
+    F.conv2d(xr, wv, padding=1).backward(gr)
+    assert max_rel(gwt, wv.grad) <= KERNEL_TOL * 5          # fp32 accumulation in both dtypes
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_transpose_against_golden_and_float64(dev, dtype, golden):
+    from insar_unet_ca_amd import engine
+    g2 = golden("g2_resample")
+    ctx = engine.Ctx(dev, dtype)
+    mod = _filled(torch.nn.ConvTranspose2d(128, 64, 2, 2)).to(dev)
+    xa = _act_from(cf.make_input((2, 128, 8, 8)), dtype, dev)
+    cat = engine.Act.alloc(2, 16, 16, 128, dtype, dev)
+    up = engine.UpPlan(ctx, mod, xa, cat.slice(64, 64), "up")
+    up.forward()
+    out = cat.slice(64, 64).nchw()
+    assert float(cat.slice(0, 64).nchw().abs().max()) == 0.0          # skip half of the concat untouched
+    dcat = engine.Act.alloc(2, 16, 16, 128, dtype, dev)
+    engine.pack_input(cf.make_grad((2, 64, 16, 16)).to(dev), dcat.slice(64, 64))
+    sink = engine.GradSink(ctx, up.params())
+    dx = engine.Act.alloc(2, 8, 8, 128, dtype, dev)
+    up.backward(dcat.slice(64, 64), sink, dx)
+    tol = FWD_TOL if dtype == torch.float32 else 2e-2
+    check_summary(g2, "convT_128_64/step0/out", out, tol)
+    check_summary(g2, "convT_128_64/step0/dx", dx.nchw(), tol)
+    check_summary(g2, "convT_128_64/step0/grad/weight", sink.view(mod.weight), tol)
+    check_summary(g2, "convT_128_64/step0/grad/bias", sink.view(mod.bias), tol)
+
+
+def test_maxpool_golden_with_ties(dev, golden):
+    import insar_unet_ca_amd as iu
+    g2 = golden("g2_resample")
+    x = torch.from_numpy(g2["pool/x"]).to(dev).requires_grad_(True)
+    out = iu.MaxPool2d(2)(x)
+    out.backward(cf.make_grad(out.shape).to(dev))
+    check_summary(g2, "pool/out", out, 0.0)
+    check_summary(g2, "pool/dx", x.grad, 0.0)            # ties route to the first max, bit-exact
+
+
+def test_outc_golden(dev, golden):
+    from insar_unet_ca_amd import engine
+    g2 = golden("g2_resample")
+    ctx = engine.Ctx(dev, torch.float32)
+    mod = _filled(torch.nn.Conv2d(64, 2, 1)).to(dev)
+    xa = _act_from(cf.make_input((2, 64, 16, 16)), torch.float32, dev)
+    oc = engine.OutConvPlan(ctx, mod, xa)
+    logits = oc.forward()
+    sink = engine.GradSink(ctx, oc.params())
+    dx = engine.Act.alloc(2, 16, 16, 64, torch.float32, dev)
+    oc.backward(cf.make_grad(logits.shape).to(dev), sink, dx)
+    check_summary(g2, "outc_64_2/step0/out", logits, 1e-5)
+    check_summary(g2, "outc_64_2/step0/dx", dx.nchw(), 1e-5)
+    check_summary(g2, "outc_64_2/step0/grad/weight", sink.view(mod.weight), 1e-5)
+    check_summary(g2, "outc_64_2/step0/grad/bias", sink.view(mod.bias), 1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# block level against the golden vectors of the reference's own classes (G1)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,c,shape,salt", [("se64", 64, (2, 64, 8, 8), 0.0), ("se128", 128, (3, 128, 4, 4), 0.3)])
+def test_se_layer_golden(dev, golden, tag, c, shape, salt):
+    import insar_unet_ca_amd as iu
+    g1 = golden("g1_blocks")
+    mod = _filled(iu.SELayer(c)).to(dev)
+    x = cf.make_input(shape, salt).to(dev).requires_grad_(True)
+    out = mod(x)
+    out.backward(cf.make_grad(out.shape).to(dev))
+    check_summary(g1, f"{tag}/step0/out", out, 1e-5)
+    check_summary(g1, f"{tag}/step0/dx", x.grad, 1e-5)
+    check_summary(g1, f"{tag}/step0/grad/fc.0.weight", mod.fc[0].weight.grad, 1e-4)
+    check_summary(g1, f"{tag}/step0/grad/fc.2.weight", mod.fc[2].weight.grad, 1e-4)
+
+
+def _relu_mask_disagreements(runner, oracle_masks):
+    """Count pre-activations whose ReLU decision differs from the oracle's (values within rounding of 0)."""
+    n = 0
+    for u, ref in zip((runner.plan.u1, runner.plan.u2), oracle_masks):
+        z = u.y.nchw() * u.scale.view(1, -1, 1, 1) + u.shift.view(1, -1, 1, 1)
+        n += int(((z > 0).cpu() != ref).sum())
+    return n
+
+
+@pytest.mark.parametrize("tag,cin,cout,use_se,shape,salt,training,steps", [
+    ("dc_2_64_se_train", 2, 64, True, (2, 2, 16, 16), 0.0, True, 2),
+    ("dc_64_128_se_train", 64, 128, True, (2, 64, 16, 16), 0.0, True, 2),
+    ("dc_64_128_se_eval", 64, 128, True, (2, 64, 16, 16), 0.0, False, 1),
+    ("dc_128_64_plain_train", 128, 64, False, (2, 128, 16, 16), 0.0, True, 1),
+    ("dc_128_64_se_ragged", 128, 64, True, (1, 128, 8, 24), 0.7, True, 1),
+])
+def test_double_conv_golden(dev, golden, tag, cin, cout, use_se, shape, salt, training, steps):
+    import insar_unet_ca_amd as iu
+    g1 = golden("g1_blocks")
+    mod = _filled(iu.DoubleConv(cin, cout, use_se=use_se)).to(dev)
+    mod.train(training)
+    need_dx = cin > 4
+    for s in range(steps):
+        sd = OrderedDict(("blk." + k, v.detach().cpu().clone()) for k, v in mod.state_dict().items())
+        for p in mod.parameters():
+            p.grad = None
+        x = cf.make_input(shape, salt).to(dev).requires_grad_(need_dx)
+        out = mod(x)
+        out.backward(cf.make_grad(out.shape).to(dev))
+        pre = f"{tag}/step{s}"
+        check_summary(g1, f"{pre}/out", out, FWD_TOL)
+        assert max_rel(out, g1[f"{pre}/out/full"]) <= 1e-4 if f"{pre}/out/full" in g1.files else True
+        for k, b in mod.named_buffers():
+            if not k.endswith("num_batches_tracked"):
+                check_summary(g1, f"{pre}/buf/{k}", b, FWD_TOL)
+            else:
+                assert int(b) == (s + 1 if training else 0)
+        # ReLU decisions of the oracle (recomputed here) vs ours decide how tight the gradient gate is
+        with torch.no_grad():
+            y1 = F.conv2d(cf.make_input(shape, salt), sd["blk.double_conv.0.weight"], sd["blk.double_conv.0.bias"], padding=1)
+            z1 = F.batch_norm(y1, sd["blk.double_conv.1.running_mean"].clone(), sd["blk.double_conv.1.running_var"].clone(),
+                              sd["blk.double_conv.1.weight"], sd["blk.double_conv.1.bias"], training=training, eps=1e-5)
+            y2 = F.conv2d(torch.relu(z1), sd["blk.double_conv.3.weight"], sd["blk.double_conv.3.bias"], padding=1)
+            z2 = F.batch_norm(y2, sd["blk.double_conv.4.running_mean"].clone(), sd["blk.double_conv.4.running_var"].clone(),
+                              sd["blk.double_conv.4.weight"], sd["blk.double_conv.4.bias"], training=training, eps=1e-5)
+        runner = list(mod._plans.plans.values())[0][0]
+        flips = _relu_mask_disagreements(runner, (z1 > 0, z2 > 0))
+        gtol = 2e-4 if flips == 0 else 5e-2
+        if need_dx:
+            check_summary(g1, f"{pre}/dx", x.grad, gtol)
+        for k, p in mod.named_parameters():
+            if k in ("double_conv.0.bias", "double_conv.3.bias") and training:
+                # exactly 0 on the HIP path (the batch mean cancels a pre-BN bias); the reference holds
+                # summation noise here
+                assert float(p.grad.abs().max()) == 0.0
+                assert float(g1[f"{pre}/grad/{k}/absmax"]) < 1e-5
+                continue
+            check_summary(g1, f"{pre}/grad/{k}", p.grad, gtol)
+
+
+# ------------------------------------------------------------------------------------------------
+# whole network against the golden vectors of the reference UNet (G3), fp32
+# ------------------------------------------------------------------------------------------------
+def _unet(dev, use_se=True, cin=2, dtype=None):
+    import insar_unet_ca_amd as iu
+    net = _filled(iu.UNet(cin, 2, use_se=use_se, compute_dtype=dtype))
+    return net.to(dev)
+
+
+def _metrics_from_device(logits, tgt, dev):
+    from insar_unet_ca_amd import _lib
+    from insar_unet_ca_amd._lib import call, ptr
+    b, k = logits.shape[0], logits.shape[1]
+    hw = logits.shape[2] * logits.shape[3]
+    counts = torch.zeros(3, k, dtype=torch.int64, device=dev)
+    lg = logits.detach().contiguous()
+    call("insar_confusion", ptr(lg), ptr(tgt), b, k, hw, 255, ptr(counts), _lib.stream_ptr())
+    c = counts.cpu().numpy()
+    return orc.metrics_from_counts(c[0], c[1], c[2])
+
+
+@pytest.mark.parametrize("tag,shape,training", [
+    ("b2_64_train", (2, 2, 64, 64), True),
+    ("b3_48x80_train", (3, 2, 48, 80), True),
+    ("b1_256_eval", (1, 2, 256, 256), False),
+    ("b1_256_train", (1, 2, 256, 256), True),
+])
+def test_unet_golden_fp32(dev, golden, tag, shape, training):
+    import insar_unet_ca_amd as iu
+    g3 = golden("g3_unet")
+    net = _unet(dev)
+    net.train(training)
+    x = cf.make_input(shape).to(dev)
+    tgt = cf.make_target((shape[0], shape[2], shape[3]), ignore_every=13).to(dev)
+    crit = iu.CrossEntropyLoss(ignore_index=255)
+    with torch.set_grad_enabled(training):
+        logits = net(x)
+        loss = crit(logits, tgt)
+    check_summary(g3, f"{tag}/logits", logits, FWD_TOL)
+    assert abs(float(loss.detach()) - float(g3[f"{tag}/loss"])) <= 1e-4 * max(1.0, abs(float(g3[f"{tag}/loss"])))
+    m = _metrics_from_device(logits, tgt, dev)
+    np.testing.assert_allclose([m[k] for k in ("acc", "miou", "mpa", "mf1")], g3[f"{tag}/metrics"], atol=2e-3)
+    if not training:
+        return
+    loss.backward()
+    for k, b in net.named_buffers():
+        if not k.endswith("num_batches_tracked"):
+            check_summary(g3, f"{tag}/buf/{k}", b, FWD_TOL)
+    # Gradient floor: on these fixtures torch's own fp32 and fp64 gradients differ by up to 0.07-0.15
+    # rel-L2 (ReLU decisions at pre-activations within rounding of 0, amplified by small-batch BN at the
+    # 4x4 bottleneck), measured in-container. Gate each parameter's gradient norm at that floor.
+    worst = 0.0
+    for k, p in net.named_parameters():
+        if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
+            assert float(p.grad.abs().max()) == 0.0
+            continue
+        nrm = float(g3[f"{tag}/grad/{k}/norm"])
+        got = float(p.grad.double().norm())
+        worst = max(worst, abs(got - nrm) / nrm)
+    assert worst <= 0.2, f"worst gradient-norm deviation {worst:.3e}"
+
+
+def test_unet_fp32_gradients_at_the_float64_noise_floor(dev):
+    """Our fp32 gradient error against a float64 oracle must be no worse than ~torch fp32's own."""
+    import insar_unet_ca_amd as iu
+    shape = (2, 2, 64, 64)
+    net = _unet(dev).train()
+    base = OrderedDict((k, v.detach().cpu().clone()) for k, v in net.state_dict().items())
+    x = cf.make_input(shape)
+    tgt = cf.make_target((2, 64, 64), ignore_every=13)
+    iu.CrossEntropyLoss(ignore_index=255)(net(x.to(dev)), tgt.to(dev)).backward()
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        work, leaves = OrderedDict(), {}
+        for k, v in base.items():
+            t = v.to(dt).clone() if v.dtype == torch.float32 else v.clone()
+            if orc.is_param(k):
+                t.requires_grad_(True)
+                leaves[k] = t
+            work[k] = t
+        orc.cross_entropy(orc.unet_forward(work, x.to(dt), True, True), tgt).backward()
+        res[dt] = {k: l.grad.double() for k, l in leaves.items()}
+    ours, torch32 = 0.0, 0.0
+    for k, p in net.named_parameters():
+        if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
+            continue
+        ref = res[torch.float64][k]
+        ours = max(ours, rel_l2(p.grad, ref))
+        torch32 = max(torch32, rel_l2(res[torch.float32][k], ref))
+    assert ours <= 3.0 * torch32 + 1e-3, f"HIP fp32 worst rel-L2 {ours:.3e} vs torch fp32 {torch32:.3e}"
+
+
+@pytest.mark.parametrize("use_se,cin", [(False, 2), (True, 1)])
+def test_unet_variants_against_oracle(dev, use_se, cin):
+    """Unet.py-equivalent (use_se=False) and the reference's default in_channels=1."""
+    import insar_unet_ca_amd as iu
+    net = _unet(dev, use_se=use_se, cin=cin).train()
+    sd = OrderedDict((k, v.detach().cpu().clone()) for k, v in net.state_dict().items())
+    x = cf.make_input((2, cin, 64, 64))
+    tgt = cf.make_target((2, 64, 64))
+    logits = net(x.to(dev))
+    loss = iu.CrossEntropyLoss(ignore_index=255)(logits, tgt.to(dev))
+    ref = orc.unet_forward(sd, x, use_se=use_se, training=True)
+    assert max_rel(logits, ref) <= FWD_TOL
+    assert abs(float(loss.detach()) - float(orc.cross_entropy(ref, tgt))) <= 1e-4
+    for k, b in net.named_buffers():       # oracle updated `sd` in place
+        if not k.endswith("num_batches_tracked"):
+            assert max_rel(b, sd[k]) <= FWD_TOL
+        else:
+            assert int(b) == int(sd[k]) == 1
+
+
+# ------------------------------------------------------------------------------------------------
+# bf16 compute path
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,shape", [("b2_64_train", (2, 2, 64, 64)), ("b3_48x80_train", (3, 2, 48, 80))])
+def test_unet_bf16_against_golden(dev, golden, tag, shape):
+    import insar_unet_ca_amd as iu
+    g3 = golden("g3_unet")
+    net = _unet(dev, dtype=torch.bfloat16).train()
+    x = cf.make_input(shape).to(dev)
+    tgt = cf.make_target((shape[0], shape[2], shape[3]), ignore_every=13).to(dev)
+    logits = net(x)
+    loss = iu.CrossEntropyLoss(ignore_index=255)(logits, tgt)
+    loss.backward()
+    ref = torch.from_numpy(g3[f"{tag}/logits/full"]) if f"{tag}/logits/full" in g3.files else None
+    if ref is not None:
+        assert max_rel(logits, ref) <= BF16_FWD_TOL
+        agree = (logits.argmax(1).cpu() == ref.argmax(1)).float().mean().item()
+        assert agree >= BF16_ARGMAX
+    else:
+        check_summary(g3, f"{tag}/logits", logits, BF16_FWD_TOL)
+    assert abs(float(loss.detach()) - float(g3[f"{tag}/loss"])) <= 2e-2
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+    for k in ("outc.weight", "conv4.double_conv.3.weight", "inc.double_conv.0.weight"):
+        nrm = float(g3[f"{tag}/grad/{k}/norm"])
+        assert abs(float(net.get_parameter(k).grad.norm()) - nrm) / nrm <= 0.35
+
+
+# ------------------------------------------------------------------------------------------------
+# loss / metrics / optimizer entry points
+# ------------------------------------------------------------------------------------------------
+def test_cross_entropy_golden(dev, golden):
+    import insar_unet_ca_amd as iu
+    g5 = golden("g5_ce")
+    lg = (cf.make_input((2, 2, 16, 16), 0.9) * 3.0).to(dev).requires_grad_(True)
+    tgt = cf.make_target((2, 16, 16), ignore_every=5).to(dev)
+    loss = iu.CrossEntropyLoss(ignore_index=255)(lg, tgt)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g5["loss"])) <= 1e-6
+    np.testing.assert_allclose(lg.grad.cpu().numpy(), g5["dlogits"], atol=2e-8)
+    lg3 = (cf.make_input((2, 3, 8, 8), 0.1) * 2.0).to(dev).requires_grad_(True)
+    loss3 = iu.CrossEntropyLoss(ignore_index=255)(lg3, torch.from_numpy(g5["target3"]).to(dev))
+    loss3.backward()
+    assert abs(float(loss3.detach()) - float(g5["loss3"])) <= 1e-6
+    np.testing.assert_allclose(lg3.grad.cpu().numpy(), g5["dlogits3"], atol=2e-8)
+
+
+def test_dice_against_oracle_definition(dev):
+    import insar_unet_ca_amd as iu
+    lg = (cf.make_input((2, 2, 16, 16), 0.9) * 3.0)
+    tgt = cf.make_target((2, 16, 16), ignore_every=5)
+    a = lg.to(dev).requires_grad_(True)
+    d = iu.DiceLoss(ignore_index=255)(a, tgt.to(dev))
+    d.backward()
+    b = lg.clone().requires_grad_(True)
+    r = orc.soft_dice_loss(b, tgt)
+    r.backward()
+    assert abs(float(d.detach()) - float(r.detach())) <= 1e-6
+    assert max_rel(a.grad, b.grad) <= 1e-4
+
+
+@pytest.mark.parametrize("case", ["three_of_four", "all_tie", "class1_absent", "ignore255"])
+def test_metrics_counts_kat(dev, golden, case):
+    g6 = golden("g6_metrics")
+    lg = torch.from_numpy(g6[f"{case}/logits"]).to(dev)
+    m = _metrics_from_device(lg, torch.from_numpy(g6[f"{case}/mask"]).to(dev), dev)
+    np.testing.assert_allclose([m[k] for k in ("acc", "miou", "mpa", "mf1")], g6[f"{case}/expect"], atol=1e-12)
+
+
+def test_confusion_counts_exact(dev):
+    lg = cf.make_input((3, 2, 32, 32), 0.4)
+    tg = cf.make_target((3, 32, 32), ignore_every=7)
+    from insar_unet_ca_amd import _lib
+    from insar_unet_ca_amd._lib import call, ptr
+    counts = torch.zeros(3, 2, dtype=torch.int64, device=dev)
+    lgd, tgd = lg.to(dev), tg.to(dev)
+    call("insar_confusion", ptr(lgd), ptr(tgd), 3, 2, 1024, 255, ptr(counts), _lib.stream_ptr())
+    tp, fp, fn = orc.confusion_counts(lg, tg, 2)
+    assert counts.cpu().tolist() == [list(map(int, tp)), list(map(int, fp)), list(map(int, fn))]
+
+
+def test_adam_kernel_against_oracle(dev):
+    import insar_unet_ca_amd as iu
+    shapes = [(7,), (64, 3, 3, 3), (1000, 33), (5, 4), (70001,)]
+    ps = [torch.nn.Parameter(cf.fill_tensor("weight", s, i).to(dev)) for i, s in enumerate(shapes)]
+    rs = [p.detach().cpu().clone() for p in ps]
+    opt = iu.Adam(ps, lr=1e-3)
+    state = {}
+    for step in range(4):
+        gl = [cf.make_grad(s, 0.1 * step + 0.3 * i) for i, s in enumerate(shapes)]
+        for p, g in zip(ps, gl):
+            p.grad = g.to(dev)
+        v0 = ps[0]._version
+        opt.step()
+        assert ps[0]._version > v0                  # weight caches key on the tensor version
+        orc.adam_update(rs, gl, state, lr=1e-3)
+    for p, r in zip(ps, rs):
+        assert max_rel(p, r) <= 1e-6
+    sd = opt.state_dict()
+    assert float(sd["state"][0]["step"]) == 4.0 and set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+def test_five_adam_steps_golden(dev, golden):
+    """G4: loss curve of 5 training steps of the reference (CE + Adam(lr=1e-4)) from identical init/batches."""
+    import insar_unet_ca_amd as iu
+    g4 = golden("g4_adam")
+    net = _unet(dev).train()
+    start = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    crit = iu.CrossEntropyLoss(ignore_index=255)
+    opt = iu.Adam(net.parameters(), lr=1e-4)
+    losses = []
+    for step in range(5):
+        x = cf.make_input((2, 2, 64, 64), salt=0.37 * step).to(dev)
+        tgt = cf.make_target((2, 64, 64)).to(dev)
+        opt.zero_grad()
+        loss = crit(net(x), tgt)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    np.testing.assert_allclose(losses, g4["losses"], rtol=1e-3)
+    # parameter drift: Adam moves every weight by ~lr per step in the direction of sign(grad)
+    for k in ("outc.weight", "conv4.double_conv.3.weight", "down4.1.double_conv.3.weight", "inc.double_conv.0.weight",
+              "up1.weight", "inc.double_conv.6.fc.0.weight"):
+        delta = net.state_dict()[k] - start[k]
+        nrm = float(g4[f"delta/{k}/norm"])
+        assert abs(float(delta.norm()) - nrm) / nrm <= 0.1, k
+    for k, v in net.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            check_summary(g4, f"final/{k}", v, 2e-3)
+
+
+# ------------------------------------------------------------------------------------------------
+# full BASELINE configuration (config 2: bf16, 16 x 2 x 256 x 256): size-independent properties
+# ------------------------------------------------------------------------------------------------
+def test_full_size_properties_bf16(dev):
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd.data import make_batch
+    torch.manual_seed(0)
+    net = iu.UNet(2, 2, True, compute_dtype=torch.bfloat16).to(dev).train()
+    crit = iu.DiceCELoss(ignore_index=255)
+    opt = iu.Adam(net.parameters(), lr=1e-4)
+    x, y = make_batch(0, 16, 256)
+    x, y = x.to(dev), y.to(dev)
+
+    def one_step():
+        opt.zero_grad()
+        logits = net(x)
+        loss = crit(logits, y)
+        loss.backward()
+        return logits, loss
+
+    l1, loss1 = one_step()
+    g1 = [p.grad.clone() for p in net.parameters()]
+    bn_before = net.inc.double_conv[1].running_mean.clone()
+    l2, loss2 = one_step()
+    # (1) no atomics anywhere: the whole step is bitwise reproducible
+    assert torch.equal(l1, l2) and float(loss1) == float(loss2)
+    assert all(torch.equal(a, p.grad) for a, p in zip(g1, net.parameters()))
+    assert not torch.equal(bn_before, net.inc.double_conv[1].running_mean)      # running stats did move
+    plan = net._plan(x)
+    # (2) halos of every activation / gradient buffer are still exactly zero
+    for a in [plan.xin, plan.x5] + plan.cat + plan.pooled + plan.dec + plan.dcat + plan.dpooled + plan.ddec:
+        assert _halo_abs(a) == 0.0
+    # (3) training-mode BN output of the first unit is normalised: z = relu(gamma*xhat + beta) with the
+    #     default gamma=1, beta=0 => pre-ReLU mean 0 / var 1 per channel
+    u = plan.enc[0].u1
+    zpre = u.y.nchw() * u.scale.view(1, -1, 1, 1) + u.shift.view(1, -1, 1, 1)
+    assert float(zpre.mean((0, 2, 3)).abs().max()) < 2e-2
+    assert float((zpre.var((0, 2, 3), unbiased=False) - 1).abs().max()) < 3e-2
+    # (4) SE gates are sigmoids; softmax-CE gradient sums to ~0 over classes
+    assert 0.0 < float(plan.enc[0].se.gate.min()) and float(plan.enc[0].se.gate.max()) < 1.0
+    # (5) gradients finite, pre-BN conv biases exactly zero, and the loss goes down when we train
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+    assert float(net.inc.double_conv[0].bias.grad.abs().max()) == 0.0
+    first = float(loss2)
+    for _ in range(8):
+        _, loss = one_step()
+        opt.step()
+    assert float(loss) < first
+
+
+def test_errors_on_device(dev):
+    import insar_unet_ca_amd as iu
+    net = iu.UNet(2, 2, True).to(dev)
+    with pytest.raises(iu.InsarError, match="multiples of 16"):
+        net(torch.zeros(1, 2, 40, 40, device=dev))
+    with pytest.raises(iu.InsarError):
+        iu.DoubleConv(48, 64).to(dev)(torch.zeros(1, 48, 16, 16, device=dev))
+    # forward under no_grad twice, then a normal step: plans are reusable
+    with torch.no_grad():
+        a = net.eval()(torch.zeros(1, 2, 32, 32, device=dev))
+        b = net(torch.zeros(1, 2, 32, 32, device=dev))
+    assert torch.equal(a, b)
