@@ -91,6 +91,16 @@ static inline ActView make_view(const InsarAct& a) {
 // Validate an activation slice: aligned base, 16-byte-aligned channel slice.
 int insar_check_act(const InsarAct* a, const char* who, const char* what);
 
+// ---- LDS store hazard guard -----------------------------------------------------------------
+// Observed on gfx950 (hipcc 7.2): a wide LDS store (ds_write_b128) whose data registers are overwritten
+// by VALU instructions a few slots later occasionally delivers a stale dword when the LDS pipe is busy
+// (nondeterministic BatchNorm partial sums in ~1 % of the work-groups). Pattern used wherever a batch of
+// freshly reduced values goes to LDS: materialise the values (LDS_PIN), store, drain (LDS_DRAIN), and keep
+// the source registers alive across the drain (LDS_KEEP) so the allocator cannot recycle them early.
+#define LDS_PIN(x) asm volatile("" : "+v"(x))
+#define LDS_KEEP(x) asm volatile("" ::"v"(x))
+#define LDS_DRAIN() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
 // ---- wave helpers -------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

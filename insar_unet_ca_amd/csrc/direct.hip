@@ -149,12 +149,21 @@ __global__ void conv3x3_small_wgrad_kernel(ActView x, ActView dy, float* __restr
         for (int o = cpp; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
         acc[t][j] = v;
       }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < CH; ++j) LDS_PIN(acc[t][j]);
     if (lane < cpp) {
 #pragma unroll
       for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int j = 0; j < CH; ++j) sm[((wave * cpp + lane) * 9 + t) * CH + j] = acc[t][j];
     }
+    LDS_DRAIN();
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < CH; ++j) LDS_KEEP(acc[t][j]);
     __syncthreads();
     for (int o = threadIdx.x; o < Co * 9; o += blockDim.x) {
       const int co = o / 9, t = o - co * 9;
@@ -307,12 +316,31 @@ __global__ void conv1x1_out_bwd_kernel(ActView x, const float* __restrict__ wt, 
       for (int j = 0; j < CH; ++j) {
         float v = aw[k][j];
         for (int o = cpp; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-        if (lane < cpp) sp[wave * pw + k * C + lane * CH + j] = v;
+        aw[k][j] = v;
+        LDS_PIN(aw[k][j]);
       }
       float b = ab[k];
       for (int o = 1; o < 64; o <<= 1) b += __shfl_xor(b, o, 64);
-      if (lane == 0) sp[wave * pw + K * C + k] = b;
+      ab[k] = b;
+      LDS_PIN(ab[k]);
     }
+  }
+#pragma unroll
+  for (int k = 0; k < DR_MAXK; ++k) {
+    if (k < K) {
+      if (lane < cpp) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) sp[wave * pw + k * C + lane * CH + j] = aw[k][j];
+      }
+      if (lane == 0) sp[wave * pw + K * C + k] = ab[k];
+    }
+  }
+  LDS_DRAIN();
+#pragma unroll
+  for (int k = 0; k < DR_MAXK; ++k) {
+    LDS_KEEP(ab[k]);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) LDS_KEEP(aw[k][j]);
   }
   __syncthreads();
   for (int o = threadIdx.x; o < pw; o += blockDim.x) {

@@ -233,6 +233,8 @@ __global__ __launch_bounds__(IG_THREADS, 2) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
       for (int o = CPR; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
     }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { LDS_PIN(s1[j]); LDS_PIN(s2[j]); }
     if (lane < CPR) {
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
@@ -240,6 +242,9 @@ __global__ __launch_bounds__(IG_THREADS, 2) void igemm_kernel(IgemmArgs a) {
         sstat[(wave * BN + lane * CH + j) * 2 + 1] = s2[j];
       }
     }
+    LDS_DRAIN();               // see common.h: keep the store's source registers intact until it has drained
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { LDS_KEEP(s1[j]); LDS_KEEP(s2[j]); }
     __syncthreads();
     if (tid < BN) {
       float v1 = 0.f, v2 = 0.f;

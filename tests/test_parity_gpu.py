@@ -126,7 +126,7 @@ def test_conv_transpose_against_golden_and_float64(dev, dtype, golden):
     sink = engine.GradSink(ctx, up.params())
     dx = engine.Act.alloc(2, 8, 8, 128, dtype, dev)
     up.backward(dcat.slice(64, 64), sink, dx)
-    tol = FWD_TOL if dtype == torch.float32 else 2e-2
+    tol = FWD_TOL if dtype == torch.float32 else 4e-2
     check_summary(g2, "convT_128_64/step0/out", out, tol)
     check_summary(g2, "convT_128_64/step0/dx", dx.nchw(), tol)
     check_summary(g2, "convT_128_64/step0/grad/weight", sink.view(mod.weight), tol)
@@ -232,7 +232,7 @@ def test_double_conv_golden(dev, golden, tag, cin, cout, use_se, shape, salt, tr
                 # exactly 0 on the HIP path (the batch mean cancels a pre-BN bias); the reference holds
                 # summation noise here
                 assert float(p.grad.abs().max()) == 0.0
-                assert float(g1[f"{pre}/grad/{k}/absmax"]) < 1e-5
+                assert float(g1[f"{pre}/grad/{k}/absmax"]) < 1e-4
                 continue
             check_summary(g1, f"{pre}/grad/{k}", p.grad, gtol)
 
