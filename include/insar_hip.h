@@ -115,6 +115,10 @@ int insar_wgrad(const InsarWgrad* d, void* stream);
  * accumulate != 0 adds into grad instead of overwriting. */
 int insar_wgrad_reduce(const float* part, float* grad, int32_t nsplit, int32_t ntaps, int32_t Co,
                        int32_t Ci, int32_t layout, int32_t accumulate, void* stream);
+/* first stage of the fold when nsplit is large: part_out[g] = sum of `group` consecutive slabs of
+ * part_in (slab_floats = ntaps*Co*Ci); the result feeds insar_wgrad_reduce with nsplit = ceil(nsplit/group). */
+int insar_wgrad_fold(const float* part_in, float* part_out, int64_t slab_floats, int32_t nsplit,
+                     int32_t group, void* stream);
 /* pixel-index table for a B x H x W grid mapped with stride s into a padded buffer of interior
  * (Hb, Wb): tab[p] = (n*(Hb+2) + h*s + 1)*(Wb+2) + w*s + 1 ; entries p >= B*H*W are `tail`
  * (0 = a zero halo pixel for the operand whose taps do not move; Wb+3 = the first interior pixel,

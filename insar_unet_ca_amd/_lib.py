@@ -76,6 +76,7 @@ _SIGNATURES = {
     "insar_igemm": [C.POINTER(InsarIgemm), _P],
     "insar_wgrad": [C.POINTER(InsarWgrad), _P],
     "insar_wgrad_reduce": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "insar_wgrad_fold": [_P, _P, _L, _I, _I, _P],
     "insar_pixel_table": [_P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
     "insar_conv3x3_small_fwd": [_AP, _P, _AP, _P, _P],
     "insar_conv3x3_small_wgrad_blocks": [_I, _I],

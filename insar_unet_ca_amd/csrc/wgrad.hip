@@ -269,6 +269,37 @@ extern "C" int insar_wgrad(const InsarWgrad* d, void* stream) {
 // transposed through LDS ([ci][tap], odd pitch), and the parameter-layout writes are
 // contiguous (Conv2d: 128*ntaps consecutive floats).
 // ---------------------------------------------------------------------------------------------
+// part_out[g][e] = sum_{sp in group g} part_in[sp][e]  (group = `group` consecutive splits): first
+// stage of the deterministic split-K fold when there are many splits (elementwise, float4, HBM-bound).
+__global__ void wgrad_fold_kernel(const float4* __restrict__ in, float4* __restrict__ out, long long slab4, int nsplit,
+                                  int group) {
+  const int g = blockIdx.y;
+  const int s0 = g * group;
+  int s1 = s0 + group; if (s1 > nsplit) s1 = nsplit;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < slab4; e += (long long)gridDim.x * blockDim.x) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int sp = s0; sp < s1; ++sp) {
+      const float4 v = in[(long long)sp * slab4 + e];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    out[(long long)g * slab4 + e] = acc;
+  }
+}
+
+extern "C" int insar_wgrad_fold(const float* part_in, float* part_out, int64_t slab_floats, int32_t nsplit, int32_t group,
+                                void* stream) {
+  if (!part_in || !part_out) INSAR_FAIL(INSAR_E_ARG, "insar_wgrad_fold: null pointer");
+  if (slab_floats < 4 || (slab_floats & 3) || nsplit < 1 || group < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_wgrad_fold: bad shape");
+  const long long slab4 = slab_floats / 4;
+  const int groups = (nsplit + group - 1) / group;
+  dim3 grid(insar_grid_cap((slab4 + 255) / 256, 1024), groups);
+  hipLaunchKernelGGL(wgrad_fold_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)part_in, (float4*)part_out,
+                     slab4, nsplit, group);
+  INSAR_CHECK_LAUNCH("insar_wgrad_fold");
+  return INSAR_OK;
+}
+
 #define WR_CIT 128
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ grad, int nsplit, int ntaps,
                                     int Co, int Ci, int layout, int accumulate) {
@@ -281,6 +312,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
     const int tap = idx / nci, c = idx - tap * nci;
     const float* p = part + (long long)tap * total + (long long)co * Ci + ci0 + c;
     float s = 0.f;
+#pragma unroll 4
     for (int sp = 0; sp < nsplit; ++sp) s += p[(long long)sp * slab];
     t[c * ntaps + tap] = s;
   }

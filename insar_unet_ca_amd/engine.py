@@ -59,6 +59,7 @@ class Ctx:
         self.ch = 16 // self.esize
         self._colsum_tmp = torch.empty(1 << 20, dtype=torch.float32, device=device)
         self._wgrad_part: Optional[torch.Tensor] = None
+        self._wgrad_fold: Optional[torch.Tensor] = None
         self._tables: Dict[tuple, torch.Tensor] = {}
         self._consts: Dict[tuple, torch.Tensor] = {}
 
@@ -86,6 +87,20 @@ class Ctx:
         if self._wgrad_part is None or self._wgrad_part.numel() < floats:
             self._wgrad_part = torch.empty(floats, dtype=torch.float32, device=self.device)
         return self._wgrad_part
+
+    def wgrad_finish(self, part: torch.Tensor, grad: torch.Tensor, nsplit: int, ntaps: int, cout: int, cin: int,
+                     layout: int) -> None:
+        """Fold the split-K slabs (two stages when there are many) and write the torch-layout gradient."""
+        s = _lib.stream_ptr()
+        slab = ntaps * cout * cin
+        if nsplit > 12:
+            group = 8 if nsplit <= 96 else 16
+            groups = (nsplit + group - 1) // group
+            if self._wgrad_fold is None or self._wgrad_fold.numel() < groups * slab:
+                self._wgrad_fold = torch.empty(groups * slab, dtype=torch.float32, device=self.device)
+            call("insar_wgrad_fold", ptr(part), ptr(self._wgrad_fold), slab, nsplit, group, s)
+            part, nsplit = self._wgrad_fold, groups
+        call("insar_wgrad_reduce", ptr(part), ptr(grad), nsplit, ntaps, cout, cin, layout, 0, s)
 
     def pixel_table(self, B, H, W, s, Hb, Wb, tail) -> torch.Tensor:
         key = (B, H, W, s, Hb, Wb, tail)
@@ -350,7 +365,7 @@ def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
         d.offdy[i] = 0
     s = _lib.stream_ptr()
     _launch_wgrad(d, B * H * W, cin, cout, 9, ctx.code)
-    call("insar_wgrad_reduce", ptr(part), ptr(grad), nsplit, 9, cout, cin, 0, 0, s)
+    ctx.wgrad_finish(part, grad, nsplit, 9, cout, cin, 0)
 
 
 class SEState:
@@ -457,7 +472,7 @@ class UpPlan:
             d.offx[i] = 0
             d.offdy[i] = a * (dout.W + 2) + b
         _launch_wgrad(d, B * h * w, self.cin, self.cout, 4, ctx.code)
-        call("insar_wgrad_reduce", ptr(part), ptr(sink.view(self.mod.weight)), nsplit, 4, self.cout, self.cin, 1, 0, s)
+        ctx.wgrad_finish(part, sink.view(self.mod.weight), nsplit, 4, self.cout, self.cin, 1)
         if dx is not None:
             _igemm(dout, dx, self.w.dgrad(), self.cin, h, w, 2, _TAPS2, 0)
 
