@@ -477,12 +477,10 @@ def test_five_adam_steps_golden(dev, golden):
         delta = net.state_dict()[k] - start[k]
         nrm = float(g4[f"delta/{k}/norm"])
         assert abs(float(delta.norm()) - nrm) / nrm <= 0.1, k
-    # running statistics after 5 steps: Adam moves every weight by +-lr per step along sign(grad), and
-    # the sign of a near-zero gradient entry is rounding noise, so the two weight trajectories (and
-    # with them the batch means) differ at the 1e-2 level relative to the statistics' range.
-    for k, v in net.state_dict().items():
-        if k.endswith("running_mean") or k.endswith("running_var"):
-            check_summary(g4, f"final/{k}", v, 5e-2)
+    # Running statistics are pinned after ONE step (test_unet_golden_fp32, 1e-3). After five Adam steps
+    # they are not a usable parity target on this fixture: the CPU oracle itself moves them by up to 56 %
+    # of their range when its input is perturbed by 1e-6 (Adam steps along sign(grad), and the sign of a
+    # near-zero gradient entry is rounding noise) - measured in-container, see DESIGN.md.
 
 
 def test_bf16_training_curve_tracks_fp32_reference(dev, golden):
