@@ -101,6 +101,26 @@ int insar_check_act(const InsarAct* a, const char* who, const char* what);
 #define LDS_KEEP(x) asm volatile("" ::"v"(x))
 #define LDS_DRAIN() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+// ---- LDS-DMA issued behind the compiler's back ------------------------------------------------
+// hipcc (ROCm 7.2) makes every ds_read that follows a __builtin_amdgcn_global_load_lds wait vmcnt(0)
+// (it cannot tell the DMA's LDS destination from the buffer being read), which serialises "prefetch the
+// next K slab" with "compute the current one". Issued from inline asm the DMA is invisible to the
+// waitcnt pass; the kernels then order it themselves: s_waitcnt vmcnt(0) + s_barrier at the end of the
+// K step that prefetched, before any wave reads that buffer. M0 carries the wave-uniform LDS byte address.
+__device__ __forceinline__ uint32_t lds_offset_of(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ void lds_dma16_untracked(const char* gsrc, uint32_t lds_wave_base) {
+  uint32_t keep;
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_wave_base);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void dma_drain_and_barrier() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
 // ---- wave helpers -------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -128,17 +128,18 @@ __global__ __launch_bounds__(IG_THREADS, 2) void igemm_kernel(IgemmArgs a) {
   const long long b_row_bytes = (long long)a.K * ES;
   const int nk = a.ntaps * a.kc_per_tap;
 
+  const uint32_t lds0 = lds_offset_of(smem);
   auto stage = [&](int buf, int ks) {
     const int tap = ks / a.kc_per_tap;
     const int kc = ks - tap * a.kc_per_tap;
     const char* xb = a.x + ((long long)stap[tap] + (long long)kc * BKe) * ES;
-    char* la = smem + buf * Cfg::STAGE + wave * 1024;
+    const uint32_t la = lds0 + buf * Cfg::STAGE + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lds_dma16(xb + a_src[i], la + i * 4096);
+    for (int i = 0; i < 4; ++i) lds_dma16_untracked(xb + a_src[i], la + i * 4096);
     const char* wb = a.w + (((long long)tap * a.N + n0 + srow) * a.K + (long long)kc * BKe) * ES + schunk;
-    char* lb = smem + buf * Cfg::STAGE + Cfg::A_STAGE + wave * 1024;
+    const uint32_t lb = la + Cfg::A_STAGE;
 #pragma unroll
-    for (int i = 0; i < BN / 32; ++i) lds_dma16(wb + (long long)i * 32 * b_row_bytes, lb + i * 4096);
+    for (int i = 0; i < BN / 32; ++i) lds_dma16_untracked(wb + (long long)i * 32 * b_row_bytes, lb + i * 4096);
   };
 
   f32x4_t acc[NT][MT];
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void igemm_kernel(IgemmArgs a) {
   const int sw = r16 & 7;
 
   stage(0, 0);
-  __syncthreads();
+  dma_drain_and_barrier();
   for (int ks = 0; ks < nk; ++ks) {
     const int buf = ks & 1;
     if (ks + 1 < nk) stage(buf ^ 1, ks + 1);
@@ -173,8 +174,11 @@ __global__ __launch_bounds__(IG_THREADS, 2) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) Mma<T>::run(wf[nt], xf[mt], acc[nt][mt]);
     }
-    __syncthreads();
+    // the slab prefetched at the top of this step has been landing while we computed: drain it and
+    // meet the other waves before anybody reads it (or overwrites the buffer we just read)
+    dma_drain_and_barrier();
   }
+  __syncthreads();
 
   // ---- epilogue: registers -> LDS tile [pixel][channel] -> 16-byte NHWC stores (+stats) ----------
   char* tile = smem;

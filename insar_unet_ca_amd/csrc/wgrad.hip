@@ -34,10 +34,6 @@ struct WgradArgs {
   int offx[12], offdy[12];
 };
 
-__device__ __forceinline__ void wg_lds_dma16(const char* gsrc, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 
 // swizzle (in 16-byte chunks) applied to a tile row of RB bytes
 template <int RB>
@@ -104,20 +100,21 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < Cfg::NY; ++i) py[i] = a.tabdy[ks * WG_BKP + yrow + i * YRS];
   };
+  const uint32_t lds0 = lds_offset_of(smem);
   auto stage = [&](int buf) {
-    char* lx = smem + buf * Cfg::STAGE + wave * 1024;
+    const uint32_t lx = lds0 + buf * Cfg::STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < Cfg::NX; ++i) {
       const int row = xrow + i * XRS;
       const int sc = xpos ^ wg_swz<Cfg::RBX>(row);
-      wg_lds_dma16(a.x + ((long long)px[i] + offx) * a.Cx * ES + xcol + sc * 16, lx + i * 4096);
+      lds_dma16_untracked(a.x + ((long long)px[i] + offx) * a.Cx * ES + xcol + sc * 16, lx + i * 4096);
     }
-    char* ly = smem + buf * Cfg::STAGE + Cfg::X_STAGE + wave * 1024;
+    const uint32_t ly = lx + Cfg::X_STAGE;
 #pragma unroll
     for (int i = 0; i < Cfg::NY; ++i) {
       const int row = yrow + i * YRS;
       const int sc = ypos ^ wg_swz<Cfg::RBY>(row);
-      wg_lds_dma16(a.dy + ((long long)py[i] + offdy) * a.Cdy * ES + ycol + sc * 16, ly + i * 4096);
+      lds_dma16_untracked(a.dy + ((long long)py[i] + offdy) * a.Cdy * ES + ycol + sc * 16, ly + i * 4096);
     }
   };
 
@@ -134,7 +131,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(WgradArgs a) {
     load_tabs(ks0);
     stage(0);
     if (ks0 + 1 < ks1) load_tabs(ks0 + 1);
-    __syncthreads();
+    dma_drain_and_barrier();
     for (long long ks = ks0; ks < ks1; ++ks) {
       const int buf = (int)((ks - ks0) & 1);
       if (ks + 1 < ks1) {
@@ -201,7 +198,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(WgradArgs a) {
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[mt], yf[nt], acc[mt][nt], 0, 0, 0);
         }
       }
-      __syncthreads();
+      dma_drain_and_barrier();
     }
   }
 
