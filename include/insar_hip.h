@@ -74,7 +74,7 @@ int insar_weight_prep(const float* in, void* out, int32_t dtype, int32_t T, int3
  * mode 1: ConvTranspose2d(k=2,s=2) forward (:112,115,118,121): N = 4*Cout, n=(a*2+b)*Cout+co
  *         is scattered to out pixel (2ho+a, 2wo+b), channel co.
  * stats (nullable): per-M-tile partial column sums of the stored output,
- *         float[insar_igemm_num_mtiles(M)][2][N] (sum, sum of squares) for BatchNorm (:82,85). */
+ *         float[insar_igemm_num_mtiles(M, N)][2][N] (sum, sum of squares) for BatchNorm (:82,85). */
 typedef struct InsarIgemm {
   InsarAct x;          /* input slice, c_len = K per tap */
   InsarAct y;          /* output slice */
@@ -88,8 +88,23 @@ typedef struct InsarIgemm {
   int32_t mode;        /* 0 | 1 */
   int8_t dy[12], dx[12];
 } InsarIgemm;
-int insar_igemm_num_mtiles(int64_t M);
+/* rows of the stats slab = number of M tiles the library will use for a GEMM with M rows and N columns
+ * (the tile height, 128 or 256 pixels, is chosen from M and N so that the grid fills the 256 CUs). */
+int insar_igemm_num_mtiles(int64_t M, int32_t N);
+int insar_igemm_tile_rows(int64_t M, int32_t N);
 int insar_igemm(const InsarIgemm* d, void* stream);
+
+/* ---- 3x3 / stride-1 convolution over the flat padded pixel space (MFMA) -------------------------------
+ * Same arithmetic as insar_igemm mode 0 with the 9 forward taps (Conv2d 3x3 pad 1 forward, :81,84, and its
+ * input gradient with flip = 1), for large grids: the three dx taps of a dy share one LDS tile of input
+ * rows, so A rows cross the L2->LDS path 3 times instead of 9. x and y cover the same B x H x W grid.
+ * w: [9][N][K] in the raster order produced by insar_weight_prep; stats (nullable):
+ * float[insar_conv3x3_flat_num_mtiles(x)][2][N]. insar_conv3x3_flat_ok() is the library's own
+ * eligibility heuristic (enough tiles to fill the chip, W,H >= 30). */
+int insar_conv3x3_flat_ok(const InsarAct* x, int32_t N);
+int insar_conv3x3_flat_num_mtiles(const InsarAct* x);
+int insar_conv3x3_flat(const InsarAct* x, const InsarAct* y, const void* w, int32_t flip, float* stats,
+                       void* stream);
 
 /* ---- weight-gradient GEMM (MFMA, split-K over pixels, no atomics) ------------------------------
  * part[split][tap][co][ci] = sum_{p in split} dy[pixB(p,tap), co] * x[pixA(p,tap), ci]

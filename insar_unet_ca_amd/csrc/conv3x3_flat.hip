@@ -1,0 +1,343 @@
+// 3x3 / stride-1 convolution (forward and input-gradient) as an implicit GEMM over the FLAT PADDED
+// pixel space, for the large-M levels of the U-Net (Unet-ChannalAttention.py:81,84 and their dgrad).
+//
+// Because activations are NHWC with a one-pixel zero halo, the padded image is one flat array of pixels
+// in which the 3x3 neighbours of pixel q are q + dy*(W+2) + dx - also across image-row boundaries. So:
+//   * one M tile = 256 consecutive padded pixels; for a given dy the A operand of all three dx taps is
+//     the SAME 256-row LDS tile read at row offsets -1/0/+1. A rows are fetched once per (K slab, dy)
+//     instead of once per tap: 3x less A traffic through the L2->LDS path, which is what bounds the
+//     per-tap kernel (igemm.hip) on these shapes (measured: ~12 TB/s of LDS-DMA traffic whatever the tile).
+//   * tiles step by 254 pixels (rows 0 and 255 only serve as neighbours), halo pixels are computed but
+//     never stored (and never counted in the BatchNorm partial sums);
+//   * A ring of 2 slots (one per dy group), B ring of 3 slots (one weight slab per tap), all by untracked
+//     LDS-DMA with counted vmcnt waits; 8 waves (4 x 2), wave tile 64 x BN/2, same MFMA / swizzle /
+//     epilogue scheme as igemm.hip.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define FL_BM 256
+#define FL_STEP (FL_BM - 2)
+#define FL_THREADS 512
+#define FL_ROWB 128
+
+struct FlatArgs {
+  const char* x; const char* w; char* y; float* stats;
+  long long P;                 // B*(H+2)*(W+2) padded pixels
+  int B, H, W;
+  int Cx, cx_off, K;
+  int Cy, cy_off, N;
+  int kc_count, flip;
+  int num_mtiles, num_ntiles;
+};
+
+template <typename T> struct FMma;
+template <> struct FMma<bf16_t> {
+  __device__ __forceinline__ static void run(const uint4& wa, const uint4& xb, f32x4_t& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, xb), acc, 0, 0, 0);
+  }
+};
+template <> struct FMma<float> {
+  __device__ __forceinline__ static void run(const uint4& wa, const uint4& xb, f32x4_t& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.x), __uint_as_float(xb.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.y), __uint_as_float(xb.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.z), __uint_as_float(xb.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.w), __uint_as_float(xb.w), acc, 0, 0, 0);
+  }
+};
+
+template <typename T, int BN>
+struct FlatCfg {
+  static constexpr int ES = sizeof(T);
+  static constexpr int BKe = FL_ROWB / ES;
+  static constexpr int A_SLOT = FL_BM * FL_ROWB;          // 32 KB
+  static constexpr int B_SLOT = BN * FL_ROWB;             // 16 / 8 KB
+  static constexpr int A_DMA = FL_BM * 8 / FL_THREADS;    // 4
+  static constexpr int B_DMA = BN * 8 / FL_THREADS;       // 2 / 1
+  static constexpr int RING = 2 * A_SLOT + 3 * B_SLOT;
+  static constexpr int PITCH = BN * ES + 16;
+  static constexpr int TILE = FL_BM * PITCH;
+  static constexpr int MAIN = RING > TILE ? RING : TILE;
+  static constexpr int ROWINFO = FL_BM * 8;               // rowOut[256] (int64)
+  static constexpr int STATB = 8 * BN * 2 * 4;
+  static constexpr int LDS_BYTES = MAIN + ROWINFO + STATB;
+};
+
+template <int N>
+__device__ __forceinline__ void fl_wait_and_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+template <typename T, int BN>
+__global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a) {
+  using Cfg = FlatCfg<T, BN>;
+  constexpr int ES = Cfg::ES, BKe = Cfg::BKe, CH = Chunk<T>::N;
+  constexpr int NT = BN / 32, MT = 4;
+  constexpr int AD = Cfg::A_DMA, BD = Cfg::B_DMA;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  long long* rowOut = (long long*)(smem + Cfg::MAIN);
+  float* sstat = (float*)(smem + Cfg::MAIN + Cfg::ROWINFO);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int t;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int mtile = t / a.num_ntiles, ntile = t - mtile * a.num_ntiles;
+  const int n0 = ntile * BN;
+  const int Wp = a.W + 2;
+  const long long q0 = (long long)mtile * FL_STEP - 1;      // tile row r <-> padded pixel q0 + r
+  const int Pm1 = (int)(a.P - 1);
+
+  if (tid < FL_BM) {
+    const long long q = q0 + tid;
+    long long ro = -1;
+    if (tid >= 1 && tid <= FL_STEP && q >= 0 && q < a.P) {
+      const int img = (a.H + 2) * Wp;
+      const int n = (int)(q / img);
+      const int rem = (int)(q - (long long)n * img);
+      const int hr = rem / Wp, wc = rem - hr * Wp;
+      if (hr >= 1 && hr <= a.H && wc >= 1 && wc <= a.W) ro = q * a.Cy + a.cy_off;
+    }
+    rowOut[tid] = ro;
+  }
+
+  // staging geometry (chunk c = i*512 + tid -> LDS row c>>3, lane-linear position c&7)
+  const int srow = tid >> 3;                                 // + 64*i
+  const int schunk = ((tid & 7) ^ (srow & 7)) * 16;
+  int a_pix[AD];
+#pragma unroll
+  for (int i = 0; i < AD; ++i) a_pix[i] = (int)q0 + srow + 64 * i;
+  const char* xbase = a.x + (long long)a.cx_off * ES + schunk;
+  const long long xpitch = (long long)a.Cx * ES;
+  const char* wbase = a.w + ((long long)(n0 + srow) * a.K) * ES + schunk;
+  const long long w_tap = (long long)a.N * a.K * ES;
+  const long long w_row64 = (long long)64 * a.K * ES;
+  const uint32_t ldsA = lds_offset_of(smem) + wave * 1024;
+  const uint32_t ldsB = ldsA + 2 * Cfg::A_SLOT;
+
+  auto stageA = [&](int slot, int kc, int dyi) {
+    const int shift = (dyi - 1) * Wp;
+    const long long koff = (long long)kc * BKe * ES;
+#pragma unroll
+    for (int i = 0; i < AD; ++i) {
+      int pix = a_pix[i] + shift;
+      pix = pix < 0 ? 0 : (pix > Pm1 ? Pm1 : pix);
+      lds_dma16_untracked(xbase + (long long)pix * xpitch + koff, ldsA + slot * Cfg::A_SLOT + i * (FL_THREADS * 16));
+    }
+  };
+  auto stageB = [&](int slot, int kc, int g9) {
+    const int tap = a.flip ? 8 - g9 : g9;
+    const char* wb = wbase + tap * w_tap + (long long)kc * BKe * ES;
+#pragma unroll
+    for (int i = 0; i < BD; ++i) lds_dma16_untracked(wb + i * w_row64, ldsB + slot * Cfg::B_SLOT + i * (FL_THREADS * 16));
+  };
+
+  f32x4_t acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int wm = wave & 3, wn = wave >> 2;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int b_frag = (wn * (BN / 2) + r16) * FL_ROWB;
+  const int swb = r16 & 7;
+  const int arow0 = wm * 64 + r16;
+
+  const int kcs = a.kc_count;
+  const int nsteps = kcs * 9, ngroups = kcs * 3;
+
+  // prologue: A(group 0), B(step 0), B(step 1)
+  stageA(0, 0, 0);
+  stageB(0, 0, 0);
+  stageB(1, 0, 1);
+  fl_wait_and_barrier<BD>();          // A(0) and B(0) landed, B(1) may still fly; rowOut visible
+
+  for (int kc = 0; kc < kcs; ++kc) {
+#pragma unroll
+    for (int dyi = 0; dyi < 3; ++dyi) {
+      const int g = kc * 3 + dyi;
+      const char* sA = smem + (g & 1) * Cfg::A_SLOT;
+#pragma unroll
+      for (int dxi = 0; dxi < 3; ++dxi) {
+        const int s = g * 3 + dxi;
+        const bool issueA = (dxi == 0) && (g + 1 < ngroups);
+        const bool issueB = (s + 2 < nsteps);
+        if (issueA) {
+          const int g1 = g + 1;
+          stageA(g1 & 1, dyi == 2 ? kc + 1 : kc, dyi == 2 ? 0 : dyi + 1);
+        }
+        if (issueB) {
+          // step s+2: tap index within its group = (dxi+2)%3, group = g + (dxi+2)/3
+          const int dx2 = (dxi + 2) % 3;
+          const int gg = g + (dxi + 2) / 3;
+          const int kc2 = gg / 3, dy2 = gg - kc2 * 3;
+          stageB(dx2, kc2, dy2 * 3 + dx2);
+        }
+        const char* sB = smem + 2 * Cfg::A_SLOT + dxi * Cfg::B_SLOT;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+          uint4 xf[MT], wf[NT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            int row = arow0 + mt * 16 + (dxi - 1);
+            row = row < 0 ? 0 : (row > FL_BM - 1 ? FL_BM - 1 : row);
+            xf[mt] = *(const uint4*)(sA + row * FL_ROWB + (((kq + 4 * sub) ^ (row & 7)) << 4));
+          }
+          const int pcb = ((kq + 4 * sub) ^ swb) << 4;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) wf[nt] = *(const uint4*)(sB + b_frag + nt * 16 * FL_ROWB + pcb);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) FMma<T>::run(wf[nt], xf[mt], acc[nt][mt]);
+        }
+        // B(s+1) (and, at the end of a dy group, A(g+1)) must have landed before the next step
+        if (dxi == 0) {
+          if (issueA && issueB) fl_wait_and_barrier<AD + BD>();
+          else if (issueB) fl_wait_and_barrier<BD>();
+          else fl_wait_and_barrier<0>();
+        } else {
+          if (issueB) fl_wait_and_barrier<BD>();
+          else fl_wait_and_barrier<0>();
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue (as igemm.hip): registers -> LDS tile -> 16-byte NHWC stores + BN partial sums ------
+  char* tile = smem;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = wm * 64 + mt * 16 + r16;
+      const int col = wn * (BN / 2) + nt * 16 + kq * 4;
+      char* p = tile + row * Cfg::PITCH + col * ES;
+      if constexpr (ES == 2) {
+        uint2 v;
+        v.x = (uint32_t)f32_to_bf16(acc[nt][mt][0]) | ((uint32_t)f32_to_bf16(acc[nt][mt][1]) << 16);
+        v.y = (uint32_t)f32_to_bf16(acc[nt][mt][2]) | ((uint32_t)f32_to_bf16(acc[nt][mt][3]) << 16);
+        *(uint2*)p = v;
+      } else {
+        *(f32x4_t*)p = acc[nt][mt];
+      }
+    }
+  __syncthreads();
+
+  constexpr int CPR = BN * ES / 16;
+  constexpr int ITER = FL_BM * CPR / FL_THREADS;
+  constexpr int RSTEP = FL_THREADS / CPR;
+  const int cc = tid % CPR;
+  const long long col_off = n0 + cc * CH;
+  float s1[CH], s2[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < ITER; ++i) {
+    const int row = i * RSTEP + tid / CPR;
+    const long long ro = rowOut[row];
+    if (ro >= 0) {
+      const uint4 u = *(const uint4*)(tile + row * Cfg::PITCH + cc * 16);
+      float f[CH];
+      Chunk<T>::unpack(u, f);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { s1[j] += f[j]; s2[j] = fmaf(f[j], f[j], s2[j]); }
+      *(uint4*)(a.y + (ro + col_off) * ES) = u;
+    }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+#pragma unroll
+      for (int o = CPR; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { LDS_PIN(s1[j]); LDS_PIN(s2[j]); }
+    if (lane < CPR) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        sstat[(wave * BN + lane * CH + j) * 2 + 0] = s1[j];
+        sstat[(wave * BN + lane * CH + j) * 2 + 1] = s2[j];
+      }
+    }
+    LDS_DRAIN();
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { LDS_KEEP(s1[j]); LDS_KEEP(s2[j]); }
+    __syncthreads();
+    if (tid < BN) {
+      float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { v1 += sstat[(w * BN + tid) * 2 + 0]; v2 += sstat[(w * BN + tid) * 2 + 1]; }
+      a.stats[((long long)mtile * 2 + 0) * a.N + n0 + tid] = v1;
+      a.stats[((long long)mtile * 2 + 1) * a.N + n0 + tid] = v2;
+    }
+  }
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+static inline long long flat_pixels(const InsarAct& x) { return (long long)x.B * (x.H + 2) * (x.W + 2); }
+static inline int flat_mtiles(long long P) { return (int)((P + FL_STEP - 1) / FL_STEP); }
+
+// The flat kernel pays for computing halo pixels and needs enough tiles to fill the chip.
+extern "C" int insar_conv3x3_flat_ok(const InsarAct* x, int32_t N) {
+  if (!x || x->W < 30 || x->H < 30) return 0;
+  const long long P = flat_pixels(*x);
+  if (P >= 0x7fffffffLL) return 0;
+  const int bn = (N % 128) == 0 ? 128 : 64;
+  return (long long)flat_mtiles(P) * (N / bn) >= 256 ? 1 : 0;
+}
+extern "C" int insar_conv3x3_flat_num_mtiles(const InsarAct* x) { return x ? flat_mtiles(flat_pixels(*x)) : 0; }
+
+template <typename T, int BN>
+static int launch_flat(FlatArgs& a, hipStream_t s) {
+  using Cfg = FlatCfg<T, BN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_flat_kernel<T, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_conv3x3_flat: hipFuncSetAttribute(%d bytes LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
+    attr_set = true;
+  }
+  a.num_ntiles = a.N / BN;
+  const long long grid = (long long)a.num_mtiles * a.num_ntiles;
+  hipLaunchKernelGGL((conv3x3_flat_kernel<T, BN>), dim3((unsigned)grid), dim3(FL_THREADS), Cfg::LDS_BYTES, s, a);
+  INSAR_CHECK_LAUNCH("insar_conv3x3_flat");
+  return INSAR_OK;
+}
+
+// y = conv3x3(x, w) over the same (B, H, W) grid. w: [9][N][K] in (dy, dx) raster order of the FORWARD
+// taps; flip != 0 walks the slabs backwards (the dgrad operand produced by insar_weight_prep keeps the
+// forward raster order of (r, s), whose spatial offsets are (1-r, 1-s)).
+extern "C" int insar_conv3x3_flat(const InsarAct* x, const InsarAct* y, const void* w, int32_t flip, float* stats,
+                                  void* stream) {
+  if (!x || !y || !w) INSAR_FAIL(INSAR_E_ARG, "insar_conv3x3_flat: null pointer");
+  int rc;
+  if ((rc = insar_check_act(x, "insar_conv3x3_flat", "x"))) return rc;
+  if ((rc = insar_check_act(y, "insar_conv3x3_flat", "y"))) return rc;
+  if (x->dtype != y->dtype) INSAR_FAIL(INSAR_E_DTYPE, "insar_conv3x3_flat: dtype differ");
+  if (x->B != y->B || x->H != y->H || x->W != y->W) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: x/y grids differ");
+  const int es = x->dtype == INSAR_BF16 ? 2 : 4;
+  const int bke = FL_ROWB / es;
+  if (x->c_len % bke) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: K=%d must be a multiple of %d", x->c_len, bke);
+  if (y->c_len % 64) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: N=%d must be a multiple of 64", y->c_len);
+  if (!insar_aligned16(w)) INSAR_FAIL(INSAR_E_ALIGN, "insar_conv3x3_flat: weights not 16-byte aligned");
+  const long long P = flat_pixels(*x);
+  if (P >= 0x7fffffffLL) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: too many pixels");
+  FlatArgs a;
+  a.x = (const char*)x->ptr; a.w = (const char*)w; a.y = (char*)y->ptr; a.stats = stats;
+  a.P = P; a.B = x->B; a.H = x->H; a.W = x->W;
+  a.Cx = x->C; a.cx_off = x->c_off; a.K = x->c_len;
+  a.Cy = y->C; a.cy_off = y->c_off; a.N = y->c_len;
+  a.kc_count = x->c_len / bke; a.flip = flip ? 1 : 0;
+  a.num_mtiles = flat_mtiles(P);
+  hipStream_t s = (hipStream_t)stream;
+  const bool wide = (a.N % 128) == 0;
+  if (x->dtype == INSAR_BF16) return wide ? launch_flat<bf16_t, 128>(a, s) : launch_flat<bf16_t, 64>(a, s);
+  return wide ? launch_flat<float, 128>(a, s) : launch_flat<float, 64>(a, s);
+}

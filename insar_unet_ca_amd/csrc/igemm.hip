@@ -24,8 +24,6 @@
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-#define IG_BM 128
-#define IG_THREADS 256
 #define IG_ROWB 128  // bytes of K per LDS row
 
 struct IgemmArgs {
@@ -60,30 +58,43 @@ template <> struct Mma<float> {
   }
 };
 
-template <typename T, int BN>
+template <typename T, int BM, int BN, int NSTAGE>
 struct IgemmCfg {
   static constexpr int ES = sizeof(T);
   static constexpr int BKe = IG_ROWB / ES;
-  static constexpr int A_STAGE = IG_BM * IG_ROWB;
+  static constexpr int WAVES_M = BM / 64;                  // each wave owns 64 x BN/2 of the tile
+  static constexpr int NWAVES = WAVES_M * 2;
+  static constexpr int THREADS = NWAVES * 64;              // == 2 * BM
+  static constexpr int A_STAGE = BM * IG_ROWB;
   static constexpr int B_STAGE = BN * IG_ROWB;
   static constexpr int STAGE = A_STAGE + B_STAGE;
-  static constexpr int PITCH = BN * ES + 16;              // epilogue tile row pitch (bytes)
-  static constexpr int TILE = IG_BM * PITCH;
-  static constexpr int MAIN = (2 * STAGE > TILE) ? 2 * STAGE : TILE;
-  static constexpr int ROWINFO = IG_BM * 8 * 2;           // rowIn[128], rowOut[128] (int64)
-  static constexpr int STATB = 4 * BN * 2 * 4;            // per-wave channel partials
-  static constexpr int TAPB = 64;                          // tap offsets (12 ints)
+  static constexpr int A_DMA = 4;                          // BM*8 chunks / THREADS
+  static constexpr int B_DMA = BN * 8 / THREADS;
+  static constexpr int PITCH = BN * ES + 16;               // epilogue tile row pitch (bytes)
+  static constexpr int TILE = BM * PITCH;
+  static constexpr int MAIN = (NSTAGE * STAGE > TILE) ? NSTAGE * STAGE : TILE;
+  static constexpr int ROWINFO = BM * 8 * 2;               // rowIn[BM], rowOut[BM] (int64)
+  static constexpr int STATB = NWAVES * BN * 2 * 4;        // per-wave channel partials
+  static constexpr int TAPB = 64;                           // tap offsets (12 ints)
   static constexpr int LDS_BYTES = MAIN + ROWINFO + STATB + TAPB;
 };
 
-template <typename T, int BN>
-__global__ __launch_bounds__(IG_THREADS, 2) void igemm_kernel(IgemmArgs a) {
-  using Cfg = IgemmCfg<T, BN>;
+// drain the LDS-DMA queue down to N outstanding per wave, then meet the other waves
+template <int N>
+__device__ __forceinline__ void dma_wait_and_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+template <typename T, int BM, int BN, int NSTAGE>
+__global__ __launch_bounds__(2 * BM, 2) void igemm_kernel(IgemmArgs a) {
+  using Cfg = IgemmCfg<T, BM, BN, NSTAGE>;
   constexpr int ES = Cfg::ES, BKe = Cfg::BKe, CH = Chunk<T>::N;
   constexpr int NT = BN / 32, MT = 4;
+  constexpr int THREADS = Cfg::THREADS, NWAVES = Cfg::NWAVES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   long long* rowIn = (long long*)(smem + Cfg::MAIN);
-  long long* rowOut = rowIn + IG_BM;
+  long long* rowOut = rowIn + BM;
   float* sstat = (float*)(smem + Cfg::MAIN + Cfg::ROWINFO);
   int* stap = (int*)(smem + Cfg::MAIN + Cfg::ROWINFO + Cfg::STATB);
 
@@ -97,14 +108,14 @@ __global__ __launch_bounds__(IG_THREADS, 2) void igemm_kernel(IgemmArgs a) {
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const int mtile = t / a.num_ntiles, ntile = t - mtile * a.num_ntiles;
-  const long long m0 = (long long)mtile * IG_BM;
+  const long long m0 = (long long)mtile * BM;
   const int n0 = ntile * BN;
 
-  if (tid == IG_THREADS - 1) {
+  if (tid == THREADS - 1) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) stap[i] = a.tapoff[i];
   }
-  if (tid < IG_BM) {
+  if (tid < BM) {
     const long long m = m0 + tid;
     const bool valid = m < a.M;
     const long long mm = valid ? m : 0;
@@ -119,27 +130,30 @@ __global__ __launch_bounds__(IG_THREADS, 2) void igemm_kernel(IgemmArgs a) {
   }
   __syncthreads();
 
-  // per-thread staging geometry: chunk q = i*256 + tid -> LDS row q>>3, lane-linear position q&7
-  const int srow = tid >> 3;                       // + 32*i
+  // per-thread staging geometry: chunk q = i*THREADS + tid -> LDS row q>>3, lane-linear position q&7
+  constexpr int RPI = THREADS / 8;                  // rows covered by one DMA instruction of the block
+  const int srow = tid >> 3;                        // + RPI*i
   const int schunk = ((tid & 7) ^ (srow & 7)) * 16; // swizzled source chunk (bytes)
-  long long a_src[4];
+  const char* a_ptr[Cfg::A_DMA];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) a_src[i] = rowIn[srow + 32 * i] * ES + schunk;
+  for (int i = 0; i < Cfg::A_DMA; ++i) a_ptr[i] = a.x + rowIn[srow + RPI * i] * ES + schunk;
   const long long b_row_bytes = (long long)a.K * ES;
+  const char* b_ptr = a.w + ((long long)(n0 + srow) * a.K) * ES + schunk;
+  const long long b_tap_bytes = (long long)a.N * a.K * ES;
   const int nk = a.ntaps * a.kc_per_tap;
-
   const uint32_t lds0 = lds_offset_of(smem);
+
   auto stage = [&](int buf, int ks) {
     const int tap = ks / a.kc_per_tap;
     const int kc = ks - tap * a.kc_per_tap;
-    const char* xb = a.x + ((long long)stap[tap] + (long long)kc * BKe) * ES;
+    const long long xoff = ((long long)stap[tap] + (long long)kc * BKe) * ES;
     const uint32_t la = lds0 + buf * Cfg::STAGE + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lds_dma16_untracked(xb + a_src[i], la + i * 4096);
-    const char* wb = a.w + (((long long)tap * a.N + n0 + srow) * a.K + (long long)kc * BKe) * ES + schunk;
+    for (int i = 0; i < Cfg::A_DMA; ++i) lds_dma16_untracked(a_ptr[i] + xoff, la + i * (THREADS * 16));
+    const char* wb = b_ptr + tap * b_tap_bytes + (long long)kc * BKe * ES;
     const uint32_t lb = la + Cfg::A_STAGE;
 #pragma unroll
-    for (int i = 0; i < BN / 32; ++i) lds_dma16_untracked(wb + (long long)i * 32 * b_row_bytes, lb + i * 4096);
+    for (int i = 0; i < Cfg::B_DMA; ++i) lds_dma16_untracked(wb + (long long)i * RPI * b_row_bytes, lb + i * (THREADS * 16));
   };
 
   f32x4_t acc[NT][MT];
@@ -148,17 +162,23 @@ __global__ __launch_bounds__(IG_THREADS, 2) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % Cfg::WAVES_M, wn = wave / Cfg::WAVES_M;
   const int r16 = lane & 15, kq = lane >> 4;
   const int a_frag = (wm * 64 + r16) * IG_ROWB;            // + mt*16*128
   const int b_frag = (wn * (BN / 2) + r16) * IG_ROWB;      // + nt*16*128
   const int sw = r16 & 7;
 
-  stage(0, 0);
-  dma_drain_and_barrier();
+  // ---- K loop: NSTAGE-deep LDS ring, NSTAGE-1 slabs in flight ------------------------------------
+  constexpr int PER = Cfg::A_DMA + Cfg::B_DMA;    // DMA instructions per wave per slab
+#pragma unroll
+  for (int p = 0; p < NSTAGE - 1; ++p)
+    if (p < nk) stage(p, p);
+  if (nk >= NSTAGE - 1) dma_wait_and_barrier<(NSTAGE - 2) * PER>();
+  else dma_wait_and_barrier<0>();
+  int buf = 0, pbuf = NSTAGE - 1;                   // pbuf = ring slot the next prefetch goes to
   for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
-    if (ks + 1 < nk) stage(buf ^ 1, ks + 1);
+    const bool more = ks + NSTAGE - 1 < nk;
+    if (more) stage(pbuf, ks + NSTAGE - 1);
     const char* sA = smem + buf * Cfg::STAGE;
     const char* sB = sA + Cfg::A_STAGE;
 #pragma unroll
@@ -174,9 +194,12 @@ __global__ __launch_bounds__(IG_THREADS, 2) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) Mma<T>::run(wf[nt], xf[mt], acc[nt][mt]);
     }
-    // the slab prefetched at the top of this step has been landing while we computed: drain it and
-    // meet the other waves before anybody reads it (or overwrites the buffer we just read)
-    dma_drain_and_barrier();
+    // slab ks+1 must have landed (and every wave must be done reading slab ks) before the next step;
+    // the NSTAGE-2 younger slabs stay in flight across the barrier.
+    if (more) dma_wait_and_barrier<(NSTAGE - 2) * PER>();
+    else dma_wait_and_barrier<0>();
+    buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+    pbuf = (pbuf + 1 == NSTAGE) ? 0 : pbuf + 1;
   }
   __syncthreads();
 
@@ -201,8 +224,8 @@ __global__ __launch_bounds__(IG_THREADS, 2) void igemm_kernel(IgemmArgs a) {
   __syncthreads();
 
   constexpr int CPR = BN * ES / 16;               // 16-byte chunks per tile row
-  constexpr int ITER = IG_BM * CPR / IG_THREADS;
-  constexpr int RSTEP = IG_THREADS / CPR;
+  constexpr int ITER = BM * CPR / THREADS;
+  constexpr int RSTEP = THREADS / CPR;
   const int cc = tid % CPR;
   const int ncol = n0 + cc * CH;
   float bias[CH];
@@ -253,26 +276,39 @@ __global__ __launch_bounds__(IG_THREADS, 2) void igemm_kernel(IgemmArgs a) {
     if (tid < BN) {
       float v1 = 0.f, v2 = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { v1 += sstat[(w * BN + tid) * 2 + 0]; v2 += sstat[(w * BN + tid) * 2 + 1]; }
+      for (int w = 0; w < NWAVES; ++w) { v1 += sstat[(w * BN + tid) * 2 + 0]; v2 += sstat[(w * BN + tid) * 2 + 1]; }
       a.stats[((long long)mtile * 2 + 0) * a.N + n0 + tid] = v1;
       a.stats[((long long)mtile * 2 + 1) * a.N + n0 + tid] = v2;
     }
   }
 }
 
-extern "C" int insar_igemm_num_mtiles(int64_t M) { return (int)((M + IG_BM - 1) / IG_BM); }
+// Tile selection: the 256-row / 8-wave / 3-slab-ring variant needs enough tiles to fill 256 CUs;
+// small-M layers (the 16x16 and 32x32 levels) keep the 128-row / 2-slab variant at 2 blocks per CU.
+static inline int igemm_bm_for(long long M, int N) {
+  const int bn = (N % 128) == 0 ? 128 : 64;
+  const long long tiles256 = ((M + 255) / 256) * (N / bn);
+  return tiles256 >= 256 ? 256 : 128;
+}
+extern "C" int insar_igemm_tile_rows(int64_t M, int32_t N) { return igemm_bm_for(M, N); }
+extern "C" int insar_igemm_num_mtiles(int64_t M, int32_t N) {
+  const int bm = igemm_bm_for(M, N);
+  return (int)((M + bm - 1) / bm);
+}
 
-template <typename T, int BN>
-static int launch_igemm(const IgemmArgs& a, hipStream_t s) {
-  using Cfg = IgemmCfg<T, BN>;
+template <typename T, int BM, int BN, int NSTAGE>
+static int launch_igemm(IgemmArgs& a, hipStream_t s) {
+  using Cfg = IgemmCfg<T, BM, BN, NSTAGE>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<T, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_igemm: hipFuncSetAttribute(%d bytes LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
     attr_set = true;
   }
+  a.num_mtiles = (int)((a.M + BM - 1) / BM);
+  a.num_ntiles = a.N / BN;
   const int grid = a.num_mtiles * a.num_ntiles;
-  hipLaunchKernelGGL((igemm_kernel<T, BN>), dim3(grid), dim3(IG_THREADS), Cfg::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, NSTAGE>), dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, a);
   INSAR_CHECK_LAUNCH("insar_igemm");
   return INSAR_OK;
 }
@@ -314,11 +350,14 @@ extern "C" int insar_igemm(const InsarIgemm* d, void* stream) {
   a.Hy = d->y.H; a.Wy = d->y.W; a.Cy = d->y.C; a.cy_off = d->y.c_off;
   a.N = d->N; a.ntaps = d->ntaps; a.mode = d->mode; a.Cout = cout;
   a.kc_per_tap = K / bke;
-  a.num_mtiles = insar_igemm_num_mtiles(a.M);
   for (int t = 0; t < 12; ++t) a.tapoff[t] = t < d->ntaps ? (d->dy[t] * (d->x.W + 2) + d->dx[t]) * d->x.C : 0;
   hipStream_t s = (hipStream_t)stream;
   const bool wide = (d->N % 128) == 0;
-  a.num_ntiles = d->N / (wide ? 128 : 64);
-  if (d->x.dtype == INSAR_BF16) return wide ? launch_igemm<bf16_t, 128>(a, s) : launch_igemm<bf16_t, 64>(a, s);
-  return wide ? launch_igemm<float, 128>(a, s) : launch_igemm<float, 64>(a, s);
+  const bool big = igemm_bm_for(a.M, d->N) == 256;
+  if (d->x.dtype == INSAR_BF16) {
+    if (big) return wide ? launch_igemm<bf16_t, 256, 128, 3>(a, s) : launch_igemm<bf16_t, 256, 64, 3>(a, s);
+    return wide ? launch_igemm<bf16_t, 128, 128, 2>(a, s) : launch_igemm<bf16_t, 128, 64, 2>(a, s);
+  }
+  if (big) return wide ? launch_igemm<float, 256, 128, 3>(a, s) : launch_igemm<float, 256, 64, 3>(a, s);
+  return wide ? launch_igemm<float, 128, 128, 2>(a, s) : launch_igemm<float, 128, 64, 2>(a, s);
 }

@@ -204,6 +204,15 @@ def _igemm(x: Act, y: Act, w: torch.Tensor, N: int, Ho: int, Wo: int, stride: in
     call("insar_igemm", C.byref(d), _lib.stream_ptr())
 
 
+def _conv3x3_flat(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[torch.Tensor]) -> None:
+    if PROFILER is not None:
+        flops = 2.0 * x.B * x.H * x.W * y.c_len * x.c_len * 9
+        tag = ("flat_f32" if x.code == _lib.F32 else "flat_bf16") + ("_bn128" if y.c_len % 128 == 0 else "_bn64")
+        PROFILER.run(tag, flops, lambda: call("insar_conv3x3_flat", x.ref, y.ref, ptr(w), flip, ptr(stats), _lib.stream_ptr()))
+        return
+    call("insar_conv3x3_flat", x.ref, y.ref, ptr(w), flip, ptr(stats), _lib.stream_ptr())
+
+
 def _launch_wgrad(d: InsarWgrad, M: int, cin: int, cout: int, ntaps: int, code: int) -> None:
     if PROFILER is not None:
         tag = "wgrad_f32" if code == _lib.F32 else "wgrad_bf16"
@@ -262,7 +271,15 @@ class ConvBN:
             raise _lib.InsarError(f"{name}: out_channels={self.cout} must be a multiple of 64 on the HIP path")
         self.M = B * H * W
         self.y = Act.alloc(B, H, W, self.cout, ctx.dtype, ctx.device)           # raw conv output (no bias)
-        self.stat_rows = B * H if self.small else call("insar_igemm_num_mtiles", self.M)
+        # large grids: flat-padded kernel (A rows shared by the three dx taps); else the per-tap implicit GEMM
+        self.flat_fwd = (not self.small) and bool(call("insar_conv3x3_flat_ok", x.ref, self.cout))
+        self.flat_bwd = (not self.small) and bool(call("insar_conv3x3_flat_ok", x.ref, self.cin))
+        if self.small:
+            self.stat_rows = B * H
+        elif self.flat_fwd:
+            self.stat_rows = call("insar_conv3x3_flat_num_mtiles", x.ref)
+        else:
+            self.stat_rows = call("insar_igemm_num_mtiles", self.M, self.cout)
         self.stats = ctx.f32(self.stat_rows, 2, self.cout)
         self.sums = ctx.f32(2, self.cout)
         self.scale, self.shift = ctx.f32(self.cout), ctx.f32(self.cout)
@@ -280,6 +297,8 @@ class ConvBN:
         if self.small:
             w = self.conv.weight.detach()
             call("insar_conv3x3_small_fwd", self.x.ref, ptr(w), self.y.ref, ptr(self.stats) if training else 0, s)
+        elif self.flat_fwd:
+            _conv3x3_flat(self.x, self.y, self.w.fwd(), 0, self.stats if training else None)
         else:
             _igemm(self.x, self.y, self.w.fwd(), self.cout, self.x.H, self.x.W, 1, _TAPS3, 0,
                    stats=self.stats if training else None)
@@ -342,7 +361,10 @@ class ConvBN:
         if dx is not None:
             if self.small:
                 raise _lib.InsarError(f"{self.name}: input gradient of the direct first-layer conv is not provided")
-            _igemm(self.dy, dx, self.w.dgrad(), self.cin, H, W, 1, _TAPS3_DGRAD, 0)
+            if self.flat_bwd:
+                _conv3x3_flat(self.dy, dx, self.w.dgrad(), 1, None)
+            else:
+                _igemm(self.dy, dx, self.w.dgrad(), self.cin, H, W, 1, _TAPS3_DGRAD, 0)
 
 
 def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:

@@ -195,7 +195,7 @@ def train_step(sd, opt_state, x, target, use_se=True, lr=1e-4, dice_weight: floa
             sd[k] = work[k]
     plist = [sd[k] for k in names]
     adam_update(plist, list(grads), opt_state, lr=lr)
-    return float(loss), logits.detach()
+    return float(loss.detach()), logits.detach()
 
 
 # --------------------------------------------------------------------------------------

@@ -62,5 +62,6 @@ def test_argument_validation_without_a_gpu():
     a = _lib.InsarAct(0, 1, 16, 16, 64, 0, 64, _lib.F32, 0)
     with pytest.raises(_lib.InsarError, match="null"):
         _lib.call("insar_maxpool2_fwd", ctypes.byref(a), ctypes.byref(a), None)
-    assert _lib.call("insar_igemm_num_mtiles", 129) == 2
+    assert _lib.call("insar_igemm_num_mtiles", 129, 128) == 2
+    assert _lib.call("insar_igemm_tile_rows", 1 << 20, 128) == 256
     assert _lib.call("insar_ce_blocks", 1) == 1

@@ -74,6 +74,10 @@ def mocked_abi(monkeypatch):
         calls.append(name)
         if name == "insar_igemm_num_mtiles":
             return (a[0] + 127) // 128
+        if name == "insar_igemm_tile_rows":
+            return 128
+        if name in ("insar_conv3x3_flat_ok", "insar_conv3x3_flat_num_mtiles"):
+            return 0
         if name == "insar_conv3x3_small_wgrad_blocks":
             return min(a[0] * a[1], 512)
         if name == "insar_conv1x1_out_bwd_blocks":

@@ -76,6 +76,8 @@ def _halo_abs(a):
     (128, 64, (1, 128, 8, 24)),      # 192 pixels: partial M tile
     (256, 256, (2, 256, 8, 8)),
     (64, 64, (3, 64, 4, 4)),         # 48 pixels: M smaller than one tile
+    (64, 64, (3, 64, 120, 200)),     # 72000 pixels: 256-row tiles (3-slab ring), ragged last tile
+    (64, 128, (4, 64, 128, 128)),    # 65536 pixels: 256-row tiles, N = 128
 ])
 def test_igemm_family_against_float64(dev, dtype, cin, cout, shape):
     from insar_unet_ca_amd import engine
@@ -86,7 +88,7 @@ def test_igemm_family_against_float64(dev, dtype, cin, cout, shape):
     ya = engine.Act.alloc(b, h, w, cout, dtype, dev)
     p = torch.nn.Parameter(cf.fill_tensor("weight", (cout, cin, 3, 3), 11).to(dev))
     gw = engine.GemmWeight(ctx, p, "conv3")
-    stats = torch.zeros(call("insar_igemm_num_mtiles", b * h * w), 2, cout, device=dev)
+    stats = torch.zeros(call("insar_igemm_num_mtiles", b * h * w, cout), 2, cout, device=dev)
     engine._igemm(xa, ya, gw.fwd(), cout, h, w, 1, engine._TAPS3, 0, stats=stats)
     xr = xa.nchw().cpu().double()                         # operands exactly as the kernel saw them
     wr = gw.fwd().float().cpu().reshape(3, 3, cout, cin).permute(2, 3, 0, 1).double()
@@ -95,8 +97,8 @@ def test_igemm_family_against_float64(dev, dtype, cin, cout, shape):
     assert max_rel(ya.nchw(), ref) <= tol
     assert _halo_abs(ya) == 0.0
     got = ya.nchw().double().cpu()
-    assert max_rel(stats.sum(0)[0], got.sum((0, 2, 3))) <= 1e-5
-    assert max_rel(stats.sum(0)[1], (got ** 2).sum((0, 2, 3))) <= 1e-5
+    assert max_rel(stats.sum(0)[0], got.sum((0, 2, 3))) <= 1e-4
+    assert max_rel(stats.sum(0)[1], (got ** 2).sum((0, 2, 3))) <= 1e-4
     ga = _act_from(cf.make_grad((b, cout, h, w)), dtype, dev)
     dxa = engine.Act.alloc(b, h, w, cin, dtype, dev)
     engine._igemm(ga, dxa, gw.dgrad(), cin, h, w, 1, engine._TAPS3_DGRAD, 0)
@@ -107,6 +109,42 @@ def test_igemm_family_against_float64(dev, dtype, cin, cout, shape):
     wv = wr.clone().requires_grad_(True)
     F.conv2d(xr, wv, padding=1).backward(gr)
     assert max_rel(gwt, wv.grad) <= KERNEL_TOL * 5          # fp32 accumulation in both dtypes
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,shape", [
+    (64, 128, (2, 64, 40, 56)),      # several 254-pixel tiles, rows shorter than a tile
+    (128, 64, (1, 128, 33, 300)),    # rows longer than a tile (a tile inside one image row), N = 64
+    (64, 64, (3, 64, 30, 30)),       # tiles straddle image boundaries
+    (256, 128, (1, 256, 32, 32)),    # four K slabs per tap
+])
+def test_conv3x3_flat_against_float64(dev, dtype, cin, cout, shape):
+    """The flat-padded 3x3 kernel (forward and flipped = input gradient), called directly so that small
+    grids exercise it too; the plans only select it when the grid fills the chip."""
+    from insar_unet_ca_amd import _lib, engine
+    from insar_unet_ca_amd._lib import call, ptr
+    ctx = engine.Ctx(dev, dtype)
+    b, _, h, w = shape
+    xa = _act_from(cf.make_input(shape), dtype, dev)
+    ya = engine.Act.alloc(b, h, w, cout, dtype, dev)
+    p = torch.nn.Parameter(cf.fill_tensor("weight", (cout, cin, 3, 3), 11).to(dev))
+    gw = engine.GemmWeight(ctx, p, "conv3")
+    rows = call("insar_conv3x3_flat_num_mtiles", xa.ref)
+    stats = torch.zeros(rows, 2, cout, device=dev)
+    call("insar_conv3x3_flat", xa.ref, ya.ref, ptr(gw.fwd()), 0, ptr(stats), _lib.stream_ptr())
+    xr = xa.nchw().cpu().double()
+    wr = gw.fwd().float().cpu().reshape(3, 3, cout, cin).permute(2, 3, 0, 1).double()
+    tol = KERNEL_TOL if dtype == torch.float32 else 6e-3
+    assert max_rel(ya.nchw(), F.conv2d(xr, wr, padding=1)) <= tol
+    assert _halo_abs(ya) == 0.0
+    got = ya.nchw().double().cpu()
+    assert max_rel(stats.sum(0)[0], got.sum((0, 2, 3))) <= 1e-4
+    assert max_rel(stats.sum(0)[1], (got ** 2).sum((0, 2, 3))) <= 1e-4
+    ga = _act_from(cf.make_grad((b, cout, h, w)), dtype, dev)
+    dxa = engine.Act.alloc(b, h, w, cin, dtype, dev)
+    call("insar_conv3x3_flat", ga.ref, dxa.ref, ptr(gw.dgrad()), 1, 0, _lib.stream_ptr())
+    assert max_rel(dxa.nchw(), F.conv_transpose2d(ga.nchw().cpu().double(), wr, padding=1)) <= tol
+    assert _halo_abs(dxa) == 0.0
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -1,0 +1,66 @@
+"""Micro-benchmark of the GEMM-class kernels on U-Net-CA layer shapes (B=16, 256x256 tiles).
+usage: python tools/gemm_bench.py [--iters N] [--only name,...] [--dtype bf16|f32]"""
+import argparse, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+from insar_unet_ca_amd import engine, _lib
+from insar_unet_ca_amd._lib import call
+
+LAYERS = {  # name: (cin, cout, hw)
+    "inc.3": (64, 64, 256), "down1.0": (64, 128, 128), "down1.3": (128, 128, 128), "down2.3": (256, 256, 64),
+    "down3.3": (512, 512, 32), "down4.3": (1024, 1024, 16), "conv1.0": (1024, 512, 32), "conv2.0": (512, 256, 64),
+    "conv3.0": (256, 128, 128), "conv4.0": (128, 64, 256),
+}
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--B", type=int, default=16)
+    ap.add_argument("--what", default="fwd,dgrad,flat,wgrad")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    ctx = engine.Ctx(dev, dtype)
+    names = [n for n in a.only.split(",") if n] or list(LAYERS)
+    what = a.what.split(",")
+    for name in names:
+        cin, cout, hw = LAYERS[name]
+        B = a.B
+        x = engine.Act.alloc(B, hw, hw, cin, dtype, dev); x.buf[:, 1:-1, 1:-1].normal_()
+        y = engine.Act.alloc(B, hw, hw, cout, dtype, dev)
+        g = engine.Act.alloc(B, hw, hw, cout, dtype, dev); g.buf[:, 1:-1, 1:-1].normal_()
+        dx = engine.Act.alloc(B, hw, hw, cin, dtype, dev)
+        p = torch.nn.Parameter(torch.randn(cout, cin, 3, 3, device=dev) * 0.05)
+        gw = engine.GemmWeight(ctx, p, "conv3")
+        M = B * hw * hw
+        stats = torch.zeros(call("insar_igemm_num_mtiles", M, cout), 2, cout, device=dev)
+        grad = torch.zeros(cout, cin, 3, 3, device=dev)
+        wf, wd = gw.fwd(), gw.dgrad()
+        flops = 2.0 * M * cin * cout * 9
+        def run(fn):
+            for _ in range(3): fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters): fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / a.iters * 1e3
+        res = []
+        if "fwd" in what:
+            us = run(lambda: engine._igemm(x, y, wf, cout, hw, hw, 1, engine._TAPS3, 0, stats=stats)); res.append(f"fwd {us:7.1f} us {flops/us/1e6:7.1f} TF")
+        if "dgrad" in what:
+            us = run(lambda: engine._igemm(g, dx, wd, cin, hw, hw, 1, engine._TAPS3_DGRAD, 0)); res.append(f"dgrad {us:7.1f} us {flops/us/1e6:7.1f} TF")
+        if "flat" in what:
+            from insar_unet_ca_amd._lib import ptr
+            rows = call("insar_conv3x3_flat_num_mtiles", x.ref)
+            st2 = torch.zeros(rows, 2, cout, device=dev)
+            us = run(lambda: call("insar_conv3x3_flat", x.ref, y.ref, ptr(wf), 0, ptr(st2), _lib.stream_ptr())); res.append(f"flat-fwd {us:7.1f} us {flops/us/1e6:7.1f} TF")
+            us = run(lambda: call("insar_conv3x3_flat", g.ref, dx.ref, ptr(wd), 1, 0, _lib.stream_ptr())); res.append(f"flat-dgrad {us:7.1f} us {flops/us/1e6:7.1f} TF")
+        if "wgrad" in what:
+            us = run(lambda: engine._wgrad_conv3(ctx, x, g, grad)); res.append(f"wgrad(+fold) {us:7.1f} us {flops/us/1e6:7.1f} TF")
+        print(f"{name:9s} {cin:4d}->{cout:4d} @{hw:3d}^2 tile_rows {call('insar_igemm_tile_rows', M, cout)}: " + " | ".join(res), flush=True)
+
+if __name__ == "__main__":
+    main()

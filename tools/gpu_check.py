@@ -104,7 +104,7 @@ def check_igemm(dtype, cin, cout, shape):
     ya = engine.Act.alloc(b, h, w, cout, dtype, DEV)
     p = torch.nn.Parameter(wt.to(DEV))
     gw = engine.GemmWeight(ctx, p, "conv3")
-    rows = call("insar_igemm_num_mtiles", b * h * w)
+    rows = call("insar_igemm_num_mtiles", b * h * w, cout)
     stats = torch.zeros(rows, 2, cout, device=DEV)
     engine._igemm(xa, ya, gw.fwd(), cout, h, w, 1, engine._TAPS3, 0, stats=stats)
     torch.cuda.synchronize()
