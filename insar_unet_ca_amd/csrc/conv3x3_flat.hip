@@ -288,6 +288,10 @@ static inline int flat_mtiles(long long P) { return (int)((P + FL_STEP - 1) / FL
 // The flat kernel pays for computing halo pixels and needs enough tiles to fill the chip.
 extern "C" int insar_conv3x3_flat_ok(const InsarAct* x, int32_t N) {
   if (!x || x->W < 30 || x->H < 30) return 0;
+  // measured (tools/gemm_bench.py, B=16): the shared-A tile wins where the GEMM is shallow (K, N <= 128:
+  // the 256^2 and 128^2 levels); for deeper K the per-tap 256-row kernel is faster (halo rows cost more
+  // than the A re-reads it saves once the weight slabs dominate the LDS traffic).
+  if (x->c_len > 128 || N > 128) return 0;
   const long long P = flat_pixels(*x);
   if (P >= 0x7fffffffLL) return 0;
   const int bn = (N % 128) == 0 ? 128 : 64;

@@ -221,9 +221,25 @@ def _launch_wgrad(d: InsarWgrad, M: int, cin: int, cout: int, ntaps: int, code: 
     call("insar_wgrad", C.byref(d), _lib.stream_ptr())
 
 
-def _wgrad_nsplit(tiles: int, ksteps: int) -> int:
-    n = max(1, min(round(1536 / max(tiles, 1)), max(1, ksteps // 4)))
-    return int(n)
+def _wgrad_nsplit(tiles: int, ksteps: int, slab_floats: int = 0, tm: int = 128, tn: int = 128, esize: int = 2) -> int:
+    """Split-K factor for the weight-gradient GEMM. The grid is tiles*nsplit work-groups at two per CU
+    (512 slots): pick the factor that minimises an estimate of
+      GEMM time / (slot quantisation efficiency * main-loop share) + slab fold traffic."""
+    lds = 2 * 64 * (tm + tn) * esize + 128            # WgradCfg::LDS_BYTES
+    slots = 256 * max(1, min(4, (160 * 1024) // lds))
+    flops_per_step = 2.0 * tm * tn * 64
+    best, best_t = 1, float("inf")
+    for n in range(1, max(1, min(ksteps // 4, 256)) + 1):
+        steps = -(-ksteps // n)
+        grid = tiles * n
+        waves = -(-grid // slots)
+        quant = grid / (waves * slots)
+        t_gemm = tiles * n * steps * flops_per_step / 700e12 / (quant * steps / (steps + 3.0))
+        t_fold = (n * slab_floats * 4 / 3e12) if n > 1 else 0.0
+        t = t_gemm + t_fold
+        if t < best_t:
+            best, best_t = n, t
+    return best
 
 
 class GradSink:
@@ -376,7 +392,7 @@ def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
     tm = 128 if (ctx.code == _lib.BF16 and cin % 128 == 0) else 64
     tn = 128 if (ctx.code == _lib.BF16 and cout % 128 == 0) else 64
     tiles = 9 * (cin // tm) * (cout // tn)
-    nsplit = _wgrad_nsplit(tiles, mpad // WG_BKP)
+    nsplit = _wgrad_nsplit(tiles, mpad // WG_BKP, 9 * cout * cin, tm, tn, ctx.esize)
     part = ctx.wgrad_part(nsplit * 9 * cout * cin)
     d = InsarWgrad()
     d.x, d.dy = x.desc, dy.desc
@@ -484,7 +500,7 @@ class UpPlan:
         tm = 128 if (ctx.code == _lib.BF16 and self.cin % 128 == 0) else 64
         tn = 128 if (ctx.code == _lib.BF16 and self.cout % 128 == 0) else 64
         tiles = 4 * (self.cin // tm) * (self.cout // tn)
-        nsplit = _wgrad_nsplit(tiles, mpad // WG_BKP)
+        nsplit = _wgrad_nsplit(tiles, mpad // WG_BKP, 4 * self.cout * self.cin, tm, tn, ctx.esize)
         part = ctx.wgrad_part(nsplit * 4 * self.cout * self.cin)
         d = InsarWgrad()
         d.x, d.dy = x.desc, dout.desc

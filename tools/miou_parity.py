@@ -24,10 +24,15 @@ def main():
     ap.add_argument("--epochs", type=int, default=10)
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--out", default="")
+    ap.add_argument("--perturb", type=float, default=0.0, help="relative input noise (oracle sensitivity study)")
+    ap.add_argument("--pseed", type=int, default=1)
     a = ap.parse_args()
     nb, nvb = a.train // a.batch, a.val // a.batch
     train = [make_batch(i * a.batch, a.batch, a.size) for i in range(nb)]
     val = [make_batch(i * a.batch, a.batch, a.size, heldout=True) for i in range(nvb)]
+    if a.perturb:
+        g = torch.Generator().manual_seed(a.pseed)
+        train = [(x * (1 + a.perturb * torch.randn(x.shape, generator=g)), y) for x, y in train]
     rng = np.random.Generator(np.random.PCG64(4242))
     history = []
     t0 = time.time()
