@@ -28,7 +28,7 @@ PEAK_BF16_TFLOPS = 2500.0             # dense MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(batch: int = 2, size: int = 256):
+def cpu_baseline(batch: int = 8, size: int = 256):
     """The oracle (CPU restatement of the reference's training step, fp32, torch/oneDNN) timed on the
     host cores of this box: one untimed + one timed step on a bounded sample."""
     from collections import OrderedDict
@@ -49,12 +49,14 @@ def cpu_baseline(batch: int = 2, size: int = 256):
     x, y = make_batch(0, batch, size)
     state = {}
     orc.train_step(sd, state, x, y, use_se=True, lr=1e-4, dice_weight=1.0)      # warm-up (primitive creation)
+    nsteps = 3
     t0 = time.time()
-    orc.train_step(sd, state, x, y, use_se=True, lr=1e-4, dice_weight=1.0)
+    for _ in range(nsteps):
+        orc.train_step(sd, state, x, y, use_se=True, lr=1e-4, dice_weight=1.0)
     dt = time.time() - t0
-    return {"value": batch / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": f"1 timed fp32 train step (fwd+Dice/CE+bwd+Adam) of the CPU oracle on {batch} synthetic "
-                      f"{size}x{size}x2 tiles, torch {torch.__version__} CPU, {cores} threads; {dt:.2f} s"}
+    return {"value": nsteps * batch / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"{nsteps} timed fp32 train steps (fwd+Dice/CE+bwd+Adam) of the CPU oracle on {batch} synthetic "
+                      f"{size}x{size}x2 tiles each, torch {torch.__version__} CPU, {cores} threads; {dt:.2f} s"}
 
 
 def main() -> int:
@@ -66,6 +68,7 @@ def main() -> int:
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--loss", default="dice_ce", choices=["dice_ce", "ce"])
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -75,6 +78,8 @@ def main() -> int:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
+    ndev = torch.cuda.device_count()
+    local_rank = local_rank % max(ndev, 1)          # rehearsal: several ranks may share the one visible GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -85,7 +90,10 @@ def main() -> int:
     from insar_unet_ca_amd.data import make_batch
 
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(0)                       # identical random init on every rank
@@ -171,23 +179,35 @@ def main() -> int:
         }
         if timer is not None:
             summ = timer.summary()
-            tag = "igemm_bf16_bn128" if args.dtype == "bf16" else "igemm_f32_bn128"
-            dom = summ.get(tag)
-            if dom:
+            dom_tag = max(summ, key=lambda k: summ[k]["ms"]) if summ else None
+            if dom_tag:
+                dom = summ[dom_tag]
                 peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+                traffic = None
+                tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+                if os.path.isfile(tpath):
+                    try:
+                        traffic = json.load(open(tpath)).get(dom_tag, {}).get("hbm_bytes_per_launch")
+                    except Exception:
+                        traffic = None
                 out["roofline"] = {
-                    "kernel": "igemm_kernel<%s,128>" % ("bf16_t" if args.dtype == "bf16" else "float"),
-                    "bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(dom["tflops"] / peak, 4), "traffic": None,
+                    "kernel": dom_tag, "bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": traffic,
+                    "flop_per_launch": round(dom["flops"] / dom["launches"], 1),
                     "avg_launch_us": round(dom["avg_us"], 2), "launches": dom["launches"],
-                    "share_of_step": round(dom["ms"] / (1e3 * elapsed), 4),
-                    "measured": "HIP events around each launch, second pass of the same %d steps "
-                                "(%.2f ms/step with events vs %.2f ms/step in the timed region)" %
+                    "share_of_step": round(dom["ms"] / (1e3 * timed_elapsed), 4),
+                    "measured": "HIP events around each launch on the launch stream, second pass of the same %d steps "
+                                "(%.2f ms/step with events vs %.2f ms/step in the timed region); traffic = rocprofv3 "
+                                "PMC (2*FETCH_SIZE + WRITE_SIZE) per launch from profiles/r01_pmc_traffic.json" %
                                 (args.steps, 1e3 * timed_elapsed / args.steps, ms),
                 }
-            out["kernel_classes"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
-                                         "tflops": round(v["tflops"], 2), "share_of_step": round(v["ms"] / (1e3 * elapsed), 4)}
-                                     for k, v in summ.items()}
+            gemm_ms = sum(v["ms"] for v in summ.values())
+            gemm_fl = sum(v["flops"] for v in summ.values())
+            out["gemm_kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
+                                       "tflops": round(v["tflops"], 2), "share_of_step": round(v["ms"] / (1e3 * timed_elapsed), 4)}
+                                   for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
+            out["gemm_total"] = {"tflops": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 2),
+                                 "share_of_step": round(gemm_ms / (1e3 * timed_elapsed), 4)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -198,7 +198,9 @@ def _igemm(x: Act, y: Act, w: torch.Tensor, N: int, Ho: int, Wo: int, stride: in
         d.dy[i], d.dx[i] = dy, dx
     if PROFILER is not None:
         flops = 2.0 * x.B * Ho * Wo * N * x.c_len * len(taps)
-        tag = ("igemm_f32" if x.code == _lib.F32 else "igemm_bf16") + ("_bn128" if N % 128 == 0 else "_bn64")
+        bm = call("insar_igemm_tile_rows", x.B * Ho * Wo, N)
+        tag = "igemm_kernel<%s, %d, %d, %d>" % ("float" if x.code == _lib.F32 else "bf16_t", bm,
+                                                128 if N % 128 == 0 else 64, 3 if bm == 256 else 2)
         PROFILER.run(tag, flops, lambda: call("insar_igemm", C.byref(d), _lib.stream_ptr()))
         return
     call("insar_igemm", C.byref(d), _lib.stream_ptr())
@@ -207,7 +209,7 @@ def _igemm(x: Act, y: Act, w: torch.Tensor, N: int, Ho: int, Wo: int, stride: in
 def _conv3x3_flat(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[torch.Tensor]) -> None:
     if PROFILER is not None:
         flops = 2.0 * x.B * x.H * x.W * y.c_len * x.c_len * 9
-        tag = ("flat_f32" if x.code == _lib.F32 else "flat_bf16") + ("_bn128" if y.c_len % 128 == 0 else "_bn64")
+        tag = "conv3x3_flat_kernel<%s, %d>" % ("float" if x.code == _lib.F32 else "bf16_t", 128 if y.c_len % 128 == 0 else 64)
         PROFILER.run(tag, flops, lambda: call("insar_conv3x3_flat", x.ref, y.ref, ptr(w), flip, ptr(stats), _lib.stream_ptr()))
         return
     call("insar_conv3x3_flat", x.ref, y.ref, ptr(w), flip, ptr(stats), _lib.stream_ptr())
@@ -215,7 +217,9 @@ def _conv3x3_flat(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[to
 
 def _launch_wgrad(d: InsarWgrad, M: int, cin: int, cout: int, ntaps: int, code: int) -> None:
     if PROFILER is not None:
-        tag = "wgrad_f32" if code == _lib.F32 else "wgrad_bf16"
+        tm = 128 if (code == _lib.BF16 and cin % 128 == 0) else 64
+        tn = 128 if (code == _lib.BF16 and cout % 128 == 0) else 64
+        tag = "wgrad_kernel<%s, %d, %d>" % ("float" if code == _lib.F32 else "bf16_t", tm, tn)
         PROFILER.run(tag, 2.0 * M * cin * cout * ntaps, lambda: call("insar_wgrad", C.byref(d), _lib.stream_ptr()))
         return
     call("insar_wgrad", C.byref(d), _lib.stream_ptr())
