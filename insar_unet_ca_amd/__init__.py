@@ -4,6 +4,8 @@ from ._lib import InsarError, LIB_PATH  # noqa: F401
 from .loss import CrossEntropyLoss, DiceCELoss, DiceLoss  # noqa: F401
 from .modules import DoubleConv, MaxPool2d, SELayer, UNet  # noqa: F401
 from .optim import Adam  # noqa: F401
+from .train import compute_metrics, train_model, validate_model  # noqa: F401
+from .train import compute_metrics, train_model, validate_model  # noqa: F401
 
 __all__ = ["UNet", "DoubleConv", "SELayer", "MaxPool2d", "CrossEntropyLoss", "DiceLoss", "DiceCELoss", "Adam",
-           "InsarError", "LIB_PATH"]
+           "compute_metrics", "train_model", "validate_model", "compute_metrics", "train_model", "validate_model", "InsarError", "LIB_PATH"]

@@ -153,3 +153,13 @@ def test_adam_state_dict_is_torch_compatible():
     kr = {k for k in ref.state_dict()["param_groups"][0]}
     assert ko == kr
     ref.load_state_dict(ours.state_dict())
+
+
+@pytest.mark.parametrize("case", ["three_of_four", "all_tie", "class1_absent", "ignore255"])
+def test_metrics_arithmetic_matches_reference_fixture(golden, case):
+    """train.metrics_from_counts (host half of compute_metrics) against the reference's own outputs (G6)."""
+    from insar_unet_ca_amd.train import metrics_from_counts
+    g6 = golden("g6_metrics")
+    tp, fp, fn = orc.confusion_counts(torch.from_numpy(g6[f"{case}/logits"]), torch.from_numpy(g6[f"{case}/mask"]), 2)
+    m = metrics_from_counts(tp, fp, fn)
+    np.testing.assert_allclose([m[k] for k in ("acc", "miou", "mpa", "mf1")], g6[f"{case}/expect"], atol=1e-12)

@@ -602,3 +602,42 @@ def test_errors_on_device(dev):
         a = net.eval()(torch.zeros(1, 2, 32, 32, device=dev))
         b = net(torch.zeros(1, 2, 32, 32, device=dev))
     assert torch.equal(a, b)
+
+
+def test_train_and_validate_loop_mirrors_reference(dev, golden, tmp_path):
+    """train_model / validate_model / compute_metrics with the reference's signatures and history keys
+    (Unet-ChannalAttention.py:215-399), metrics read back once per epoch."""
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd.data import SyntheticTiles
+    from insar_unet_ca_amd.train import compute_metrics, train_model, validate_model
+    g6 = golden("g6_metrics")
+    for case in ("three_of_four", "all_tie", "class1_absent", "ignore255"):
+        m = compute_metrics(torch.from_numpy(g6[f"{case}/logits"]).to(dev), torch.from_numpy(g6[f"{case}/mask"]).to(dev), 2)
+        np.testing.assert_allclose([m[k] for k in ("acc", "miou", "mpa", "mf1")], g6[f"{case}/expect"], atol=1e-12)
+    torch.manual_seed(0)
+    net = iu.UNet(2, 2, True)
+    train_dl = torch.utils.data.DataLoader(SyntheticTiles(16, 32), batch_size=8, shuffle=False)
+    val_dl = torch.utils.data.DataLoader(SyntheticTiles(8, 32, heldout=True), batch_size=8, shuffle=False)
+    path = str(tmp_path / "ckpt" / "best.pth")
+    hist = train_model(net, train_dl, val_dl, iu.CrossEntropyLoss(ignore_index=255), iu.Adam(net.parameters(), lr=1e-3),
+                       dev, num_epochs=2, model_save_path=path, verbose=False)
+    assert len(hist) == 2
+    assert set(hist[0]) == {"epoch", "train_loss", "train_acc", "train_miou", "train_mpa", "train_mf1",
+                            "val_loss", "val_acc", "val_miou", "val_mpa", "val_mf1"}
+    assert hist[1]["train_loss"] < hist[0]["train_loss"]
+    assert net.training                                  # validate_model restores train mode (:316)
+    # the checkpoint is a plain state_dict with the reference's 154 keys and loads into a fresh model
+    sd = torch.load(path)
+    assert len(sd) == 154
+    fresh = iu.UNet(2, 2, True)
+    fresh.load_state_dict(sd)
+    # validation metrics agree with the oracle's compute_metrics on the same logits
+    net.eval()
+    x, y = next(iter(val_dl))
+    with torch.no_grad():
+        lg = net(x.to(dev))
+    ours = compute_metrics(lg, y.to(dev), 2)
+    ref = orc.compute_metrics(lg.cpu(), y, 2)
+    np.testing.assert_allclose([ours[k] for k in ref], [ref[k] for k in ref], atol=1e-12)
+    v = validate_model(net, val_dl, iu.CrossEntropyLoss(ignore_index=255), dev, verbose=False)
+    assert abs(v["val_miou"] - ours["miou"]) < 1e-12     # one batch: weighted mean == the batch value
