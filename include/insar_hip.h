@@ -66,6 +66,11 @@ int insar_unpack_nchw(const InsarAct* src, float* dst, void* stream);
 int insar_weight_prep(const float* in, void* out, int32_t dtype, int32_t T, int32_t N, int32_t K,
                       int64_t st, int64_t sn, int64_t sk, void* stream);
 
+/* batched form, one launch for every weight of the network. jobs (device): int64[njobs][10] =
+ * {in*, out*, T, N, K, st, sn, sk, first_tile, dtype}; a job owns T*ceil(N/32)*ceil(K/32) consecutive tiles
+ * starting at first_tile; total_tiles = sum over jobs. */
+int insar_weight_prep_batch(const int64_t* jobs, int32_t njobs, int64_t total_tiles, void* stream);
+
 /* ---- implicit-GEMM convolution family (MFMA) ------------------------------------------------
  * y[pix(m), n] = sum_{tap, k} x[in_pix(m, tap), k] * w[tap][n][k]  (+ bias[n])
  *   m enumerates the out.B x Ho x Wo grid row-major; in_pix = (ho*stride + dy[tap], wo*stride + dx[tap]).
@@ -154,13 +159,17 @@ int insar_conv3x3_small_wgrad(const InsarAct* x, const InsarAct* dy, float* part
 int insar_colsum(const float* part, float* out, int32_t segments, int64_t rows, int32_t cols,
                  int32_t accumulate, float* tmp, int64_t tmp_floats, void* stream);
 
+/* first stage only: out[ceil(rows/rps)][cols]; insar_bn_finalize folds the remaining rows itself. */
+int insar_colsum_partial(const float* part, float* out, int64_t rows, int32_t cols, int32_t rps,
+                         void* stream);
+
 /* ---- BatchNorm2d (+ReLU) (:82-83, :85-86) -------------------------------------------------------
- * finalize: from the column sums part[2][C] (sum, sum of squares; insar_colsum of the stats slabs) of
- * the raw (bias-free) conv output over `count` pixels: batch mean/var -> scale = gamma*invstd, shift = beta - mean*scale; running stats
+ * finalize: from `rows` (<= 4096) remaining partial rows part[rows][2][C] (sum, sum of squares) of
+ * the raw (bias-free) conv output over `count` pixels (larger slabs go through insar_colsum first): batch mean/var -> scale = gamma*invstd, shift = beta - mean*scale; running stats
  * (momentum, unbiased var; the conv bias is added to the mean) and num_batches_tracked.
  * training == 0: scale/shift from the running stats (+ conv bias), slabs ignored. */
 typedef struct InsarBnFinalize {
-  const float* part; int64_t count; int32_t C; int32_t training;
+  const float* part; int64_t rows; int64_t count; int32_t C; int32_t training;
   const float* conv_bias; const float* gamma; const float* beta;
   float* running_mean; float* running_var; int64_t* num_batches_tracked;
   float momentum; float eps;
@@ -181,10 +190,11 @@ int insar_se_squeeze(const InsarAct* y, const float* scale, const float* shift, 
 /* excitation: mean -> Linear(C,C/r) -> ReLU -> Linear(C/r,C) -> Sigmoid (two bias-free Linears,
  * :54-59). Saves sq[B][C] (the squeezed mean), hid[B][Cr] (post-ReLU), gate[B][C]. */
 typedef struct InsarSeFwd {
-  const float* pooled; /* [B][2][C]: per image sum of mask, sum of mask*y (insar_colsum of the squeeze slabs) */
-  int32_t B, H, W, C, Cr; int32_t _pad;
+  const float* part;   /* squeeze slabs [B][rows][2][C] (insar_se_squeeze: rows = H), folded in-kernel */
+  int32_t B, H, W, C, Cr; int32_t rows;
   const float* scale; const float* shift;
   const float* w1; /* (Cr, C) */ const float* w2; /* (C, Cr) */
+  float* pooled; /* out [B][2][C]: per image sum of mask, sum of mask*y (kept for backward) */
   float* sq; float* hid; float* gate;
 } InsarSeFwd;
 int insar_se_excite(const InsarSeFwd* d, void* stream);
@@ -193,8 +203,8 @@ int insar_se_excite(const InsarSeFwd* d, void* stream);
  * reduce: part[B*H][2][C] = per (n,row) sums over w of  g*mask  and  g*mask*y , g = dout (T).  */
 int insar_bnrelu_bwd_reduce(const InsarAct* dout, const InsarAct* y, const float* scale,
                             const float* shift, float* part, int32_t relu, void* stream);
-/* coefficient kernels: turn the per-image reduced sums red[B][2][C] (insar_colsum of the reduce
- * slabs) into everything the apply pass needs.
+/* coefficient kernels: turn the reduce slabs red[B][rows][2][C] (insar_bnrelu_bwd_reduce: rows = H;
+ * folded per image in-kernel) into everything the apply pass needs.
  *  with SE:  ds -> MLP backward (dW1, dW2, dsq);  g_eff = (dout*gate + dsq/HW) on the ReLU mask
  *  dgamma/dbeta; coefB[B][C] = dsq/HW and per-channel k1[C] = dbeta/N, k2[C] = dgamma/N (0 in eval):
  *    dy = scale_c * ( (dout*gate + coefB)*mask - k1 - xhat*k2 ).
@@ -210,8 +220,8 @@ typedef struct InsarBnSeBwd {
   float* coefB; float* k1; float* k2;
   int32_t accumulate; int32_t _pad;
 } InsarBnSeBwd;
-int insar_bnse_bwd_coef(const InsarBnSeBwd* d, const float* red, const float* scale, const float* shift,
-                        float* ws, float* dconv_bias, int32_t training, void* stream);
+int insar_bnse_bwd_coef(const InsarBnSeBwd* d, const float* red, int32_t rows, const float* scale,
+                        const float* shift, float* ws, float* dconv_bias, int32_t training, void* stream);
 int insar_bnrelu_bwd_apply(const InsarAct* dout, const InsarAct* y, const float* scale,
                            const float* shift, const float* mean, const float* invstd,
                            const float* gate, const float* coefB, const float* k1,

@@ -37,7 +37,7 @@ class InsarWgrad(C.Structure):
 
 
 class InsarBnFinalize(C.Structure):
-    _fields_ = [("part", C.c_void_p), ("count", C.c_int64), ("C", C.c_int32), ("training", C.c_int32),
+    _fields_ = [("part", C.c_void_p), ("rows", C.c_int64), ("count", C.c_int64), ("C", C.c_int32), ("training", C.c_int32),
                 ("conv_bias", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
                 ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
                 ("num_batches_tracked", C.c_void_p), ("momentum", C.c_float), ("eps", C.c_float),
@@ -45,10 +45,10 @@ class InsarBnFinalize(C.Structure):
 
 
 class InsarSeFwd(C.Structure):
-    _fields_ = [("pooled", C.c_void_p), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("C", C.c_int32), ("Cr", C.c_int32), ("_pad", C.c_int32),
+    _fields_ = [("part", C.c_void_p), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("C", C.c_int32), ("Cr", C.c_int32), ("rows", C.c_int32),
                 ("scale", C.c_void_p), ("shift", C.c_void_p), ("w1", C.c_void_p), ("w2", C.c_void_p),
-                ("sq", C.c_void_p), ("hid", C.c_void_p), ("gate", C.c_void_p)]
+                ("pooled", C.c_void_p), ("sq", C.c_void_p), ("hid", C.c_void_p), ("gate", C.c_void_p)]
 
 
 class InsarBnSeBwd(C.Structure):
@@ -72,6 +72,7 @@ _SIGNATURES = {
     "insar_pack_nchw": [_P, _AP, _P],
     "insar_unpack_nchw": [_AP, _P, _P],
     "insar_weight_prep": [_P, _P, _I, _I, _I, _I, _L, _L, _L, _P],
+    "insar_weight_prep_batch": [_P, _I, _L, _P],
     "insar_igemm_num_mtiles": [_L, _I],
     "insar_igemm_tile_rows": [_L, _I],
     "insar_igemm": [C.POINTER(InsarIgemm), _P],
@@ -86,12 +87,13 @@ _SIGNATURES = {
     "insar_conv3x3_small_wgrad_blocks": [_I, _I],
     "insar_conv3x3_small_wgrad": [_AP, _AP, _P, _P],
     "insar_colsum": [_P, _P, _I, _L, _I, _I, _P, _L, _P],
+    "insar_colsum_partial": [_P, _P, _L, _I, _I, _P],
     "insar_bn_finalize": [C.POINTER(InsarBnFinalize), _P],
     "insar_bn_relu_apply": [_AP, _P, _P, _P, _AP, _I, _P],
     "insar_se_squeeze": [_AP, _P, _P, _P, _I, _P],
     "insar_se_excite": [C.POINTER(InsarSeFwd), _P],
     "insar_bnrelu_bwd_reduce": [_AP, _AP, _P, _P, _P, _I, _P],
-    "insar_bnse_bwd_coef": [C.POINTER(InsarBnSeBwd), _P, _P, _P, _P, _P, _I, _P],
+    "insar_bnse_bwd_coef": [C.POINTER(InsarBnSeBwd), _P, _I, _P, _P, _P, _P, _I, _P],
     "insar_bnrelu_bwd_apply": [_AP, _AP, _P, _P, _P, _P, _P, _P, _P, _P, _AP, _I, _P],
     "insar_maxpool2_fwd": [_AP, _AP, _P],
     "insar_maxpool2_bwd": [_AP, _AP, _AP, _I, _P],

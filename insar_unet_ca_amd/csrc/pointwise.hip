@@ -169,6 +169,62 @@ extern "C" int insar_weight_prep(const float* in, void* out, int32_t dtype, int3
   return INSAR_OK;
 }
 
+// Batched form: one launch re-lays out every weight of the network. jobs: int64[njobs][10] =
+// {in*, out*, T, N, K, st, sn, sk, first_tile, dtype}; tiles of 32x32 (n x k) per tap, numbered job after job.
+template <typename T>
+__device__ __forceinline__ void weight_prep_tile(const float* __restrict__ in, T* __restrict__ out, int N, int K, int64_t st,
+                                                 int64_t sn, int64_t sk, int t, int n0, int k0, float (*tile)[33]) {
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const bool k_fast_in = sk <= sn;
+  for (int j = ty; j < 32; j += 8) {
+    int n = k_fast_in ? n0 + j : n0 + tx;
+    int k = k_fast_in ? k0 + tx : k0 + j;
+    float v = 0.f;
+    if (n < N && k < K) v = in[(int64_t)t * st + (int64_t)n * sn + (int64_t)k * sk];
+    if (k_fast_in) tile[j][tx] = v; else tile[tx][j] = v;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int n = n0 + j, k = k0 + tx;
+    if (n < N && k < K) {
+      float v = tile[j][tx];
+      int64_t o = ((int64_t)t * N + n) * K + k;
+      if constexpr (sizeof(T) == 2) ((uint16_t*)out)[o] = f32_to_bf16(v); else ((float*)out)[o] = v;
+    }
+  }
+}
+
+__global__ void weight_prep_batch_kernel(const int64_t* __restrict__ jobs, int njobs) {
+  __shared__ float tile[32][33];
+  __shared__ int sjob;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = njobs - 1;                       // last job whose first_tile <= blockIdx.x
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (jobs[mid * 10 + 8] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    sjob = lo;
+  }
+  __syncthreads();
+  const int64_t* j = jobs + sjob * 10;
+  const float* in = (const float*)j[0];
+  void* out = (void*)j[1];
+  const int N = (int)j[3], K = (int)j[4];
+  const int local = (int)(blockIdx.x - j[8]);
+  const int kt = (K + 31) / 32, nt = (N + 31) / 32;
+  const int t = local / (kt * nt), rem = local - t * kt * nt;
+  const int n0 = (rem / kt) * 32, k0 = (rem % kt) * 32;
+  if (j[9] == INSAR_BF16) weight_prep_tile<bf16_t>(in, (bf16_t*)out, N, K, j[5], j[6], j[7], t, n0, k0, tile);
+  else weight_prep_tile<float>(in, (float*)out, N, K, j[5], j[6], j[7], t, n0, k0, tile);
+}
+
+extern "C" int insar_weight_prep_batch(const int64_t* jobs, int32_t njobs, int64_t total_tiles, void* stream) {
+  if (!jobs || njobs < 1 || total_tiles < 1 || total_tiles > 0x7fffffffLL) INSAR_FAIL(INSAR_E_ARG, "insar_weight_prep_batch: bad arguments");
+  hipLaunchKernelGGL(weight_prep_batch_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, jobs, njobs);
+  INSAR_CHECK_LAUNCH("insar_weight_prep_batch");
+  return INSAR_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // segmented column sums of partial slabs: out[s][c] (+)= sum_{r in split} part[s][r][c]
 // grid = (col blocks of 64, row splits, segments); block = 64 cols x 4 row lanes.
@@ -226,6 +282,19 @@ extern "C" int insar_colsum(const float* part, float* out, int32_t segments, int
   return INSAR_OK;
 }
 
+// First stage only: out[split][c] = sum of rows [split*rps, (split+1)*rps) of part[rows][cols]; the consumer
+// (insar_bn_finalize) folds the ceil(rows/rps) remaining rows itself.
+extern "C" int insar_colsum_partial(const float* part, float* out, int64_t rows, int32_t cols, int32_t rps, void* stream) {
+  if (!part || !out) INSAR_FAIL(INSAR_E_ARG, "insar_colsum_partial: null pointer");
+  if (rows < 1 || cols < 1 || rps < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_colsum_partial: bad shape");
+  const int64_t nsplit = (rows + rps - 1) / rps;
+  if (nsplit > 65535) INSAR_FAIL(INSAR_E_SHAPE, "insar_colsum_partial: too many splits");
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, (unsigned)nsplit, 1), dim3(256), 0, (hipStream_t)stream, part, out,
+                     rows, cols, rps, 0, (int64_t)cols);
+  INSAR_CHECK_LAUNCH("insar_colsum_partial");
+  return INSAR_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // BatchNorm finalize (Unet-ChannalAttention.py:82,85; nn.BatchNorm2d training/eval semantics)
 // sums[0][c] = sum y_raw, sums[1][c] = sum y_raw^2 over `count` pixels (y_raw = conv w/o bias).
@@ -238,7 +307,11 @@ __global__ void bn_finalize_kernel(InsarBnFinalize d) {
   float mean_raw, invstd;
   if (d.training) {
     const double n = (double)d.count;
-    const double s1 = d.part[c], s2 = d.part[d.C + c];
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t r = 0; r < d.rows; ++r) {          // fold the (few) remaining partial rows: [rows][2][C]
+      s1 += (double)d.part[(r * 2 + 0) * d.C + c];
+      s2 += (double)d.part[(r * 2 + 1) * d.C + c];
+    }
     const double m = s1 / n;
     double var = s2 / n - m * m;
     if (var < 0) var = 0;
@@ -264,9 +337,10 @@ __global__ void bn_finalize_kernel(InsarBnFinalize d) {
 extern "C" int insar_bn_finalize(const InsarBnFinalize* d, void* stream) {
   if (!d || !d->gamma || !d->beta || !d->scale || !d->shift || !d->mean || !d->invstd)
     INSAR_FAIL(INSAR_E_ARG, "insar_bn_finalize: null pointer");
-  if (d->training && (!d->part || d->count < 1)) INSAR_FAIL(INSAR_E_ARG, "insar_bn_finalize: training needs sums");
+  if (d->training && (!d->part || d->count < 1 || d->rows < 1 || d->rows > 4096))
+    INSAR_FAIL(INSAR_E_ARG, "insar_bn_finalize: training needs 1..4096 rows of partial sums");
   if (!d->training && (!d->running_mean || !d->running_var)) INSAR_FAIL(INSAR_E_ARG, "insar_bn_finalize: eval needs running stats");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->C + 127) / 128), dim3(128), 0, (hipStream_t)stream, *d);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->C + 63) / 64), dim3(64), 0, (hipStream_t)stream, *d);
   INSAR_CHECK_LAUNCH("insar_bn_finalize");
   return INSAR_OK;
 }
@@ -424,6 +498,34 @@ extern "C" int insar_bnrelu_bwd_reduce(const InsarAct* dout, const InsarAct* y, 
   return INSAR_OK;
 }
 
+// Sum `rows` rows of a [rows][cols] fp32 slab into out[cols] (LDS), all threads of the block cooperating:
+// columns across lanes (coalesced), row lanes when cols < blockDim. `scratch` needs blockDim floats.
+__device__ __forceinline__ void block_colsum(const float* __restrict__ slab, int rows, int cols, float* out, float* scratch) {
+  const int nt = blockDim.x;
+  if (cols >= nt) {
+    for (int c = threadIdx.x; c < cols; c += nt) {
+      float a = 0.f;
+      for (int r = 0; r < rows; ++r) a += slab[(int64_t)r * cols + c];
+      out[c] = a;
+    }
+    __syncthreads();
+  } else {
+    const int lanes = nt / cols;                       // row lanes (cols is a power of two <= nt)
+    const int c = threadIdx.x % cols, rl = threadIdx.x / cols;
+    float a = 0.f;
+    if (rl < lanes)
+      for (int r = rl; r < rows; r += lanes) a += slab[(int64_t)r * cols + c];
+    scratch[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x < cols) {
+      float t = 0.f;
+      for (int l = 0; l < lanes; ++l) t += scratch[l * cols + threadIdx.x];
+      out[threadIdx.x] = t;
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // SE excitation (Unet-ChannalAttention.py:54-59,65-68): one block per image.
 // pooled[n][0][c] = sum mask, pooled[n][1][c] = sum mask*y  =>  mean_hw(z) = (scale*q1 + shift*q0)/HW
@@ -432,11 +534,17 @@ __global__ void se_excite_kernel(InsarSeFwd d) {
   extern __shared__ float sm[];
   float* sq = sm;            // [C]
   float* hid = sm + d.C;     // [Cr]
+  float* pool = hid + d.Cr;  // [2C]
+  float* scratch = pool + 2 * d.C;   // [blockDim]
   const int n = blockIdx.x;
   const float inv_hw = 1.f / ((float)d.H * (float)d.W);
+  // fold this image's squeeze rows: part[(n*rows + r)][2][C]
+  block_colsum(d.part + (int64_t)n * d.rows * 2 * d.C, d.rows, 2 * d.C, pool, scratch);
   for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
-    const float q0 = d.pooled[((int64_t)n * 2 + 0) * d.C + c];
-    const float q1 = d.pooled[((int64_t)n * 2 + 1) * d.C + c];
+    const float q0 = pool[c];
+    const float q1 = pool[d.C + c];
+    d.pooled[((int64_t)n * 2 + 0) * d.C + c] = q0;
+    d.pooled[((int64_t)n * 2 + 1) * d.C + c] = q1;
     const float m = (d.scale[c] * q1 + d.shift[c] * q0) * inv_hw;
     sq[c] = m;
     d.sq[(int64_t)n * d.C + c] = m;
@@ -462,10 +570,11 @@ __global__ void se_excite_kernel(InsarSeFwd d) {
 }
 
 extern "C" int insar_se_excite(const InsarSeFwd* d, void* stream) {
-  if (!d || !d->pooled || !d->scale || !d->shift || !d->w1 || !d->w2 || !d->sq || !d->hid || !d->gate)
+  if (!d || !d->part || !d->pooled || !d->scale || !d->shift || !d->w1 || !d->w2 || !d->sq || !d->hid || !d->gate)
     INSAR_FAIL(INSAR_E_ARG, "insar_se_excite: null pointer");
-  if (d->B < 1 || d->C < 1 || d->Cr < 1 || d->C > 8192) INSAR_FAIL(INSAR_E_SHAPE, "insar_se_excite: bad shape");
-  size_t lds = (size_t)(d->C + d->Cr) * sizeof(float);
+  if (d->B < 1 || d->C < 1 || d->Cr < 1 || d->C > 4096 || d->rows < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_se_excite: bad shape");
+  if (2 * d->C < 256 && (256 % (2 * d->C))) INSAR_FAIL(INSAR_E_SHAPE, "insar_se_excite: C must be a power of two below 128");
+  size_t lds = (size_t)(3 * d->C + d->Cr + 256) * sizeof(float);
   hipLaunchKernelGGL(se_excite_kernel, dim3(d->B), dim3(256), lds, (hipStream_t)stream, *d);
   INSAR_CHECK_LAUNCH("insar_se_excite");
   return INSAR_OK;
@@ -481,7 +590,7 @@ extern "C" int insar_se_excite(const InsarSeFwd* d, void* stream) {
 // ---------------------------------------------------------------------------------------------
 struct BnSeBwdArgs {
   InsarBnSeBwd d;
-  const float* red; const float* scale; const float* shift;
+  const float* red; int rows; const float* scale; const float* shift;
   float* ws; float* dconv_bias; int training;
 };
 
@@ -490,7 +599,10 @@ __global__ void bnse_bwd_stage1(BnSeBwdArgs a) {
   const InsarBnSeBwd& d = a.d;
   float* du_s = sm;              // [C]
   float* dt_s = sm + d.C;        // [Cr]
+  float* red_s = dt_s + d.Cr + 1;    // [2C]: this image's folded (P2, Q)
+  float* scratch = red_s + 2 * d.C;  // [blockDim]
   const int n = blockIdx.x;
+  block_colsum(a.red + (int64_t)n * a.rows * 2 * d.C, a.rows, 2 * d.C, red_s, scratch);
   float* du_g = a.ws + (int64_t)n * d.C;
   float* dt_g = a.ws + (int64_t)d.B * d.C + (int64_t)n * d.Cr;
   float* tb_g = a.ws + (int64_t)d.B * (d.C + d.Cr) + (int64_t)n * d.C;
@@ -498,8 +610,8 @@ __global__ void bnse_bwd_stage1(BnSeBwdArgs a) {
   const float inv_hw = 1.f / ((float)d.H * (float)d.W);
   if (d.use_se) {
     for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
-      const float p2 = a.red[((int64_t)n * 2 + 0) * d.C + c];
-      const float q = a.red[((int64_t)n * 2 + 1) * d.C + c];
+      const float p2 = red_s[c];
+      const float q = red_s[d.C + c];
       const float ds = a.scale[c] * q + a.shift[c] * p2;         // sum dout * z
       const float s = d.gate[(int64_t)n * d.C + c];
       const float du = ds * s * (1.f - s);
@@ -519,8 +631,8 @@ __global__ void bnse_bwd_stage1(BnSeBwdArgs a) {
     __syncthreads();
   }
   for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
-    const float p2 = a.red[((int64_t)n * 2 + 0) * d.C + c];
-    const float q = a.red[((int64_t)n * 2 + 1) * d.C + c];
+    const float p2 = red_s[c];
+    const float q = red_s[d.C + c];
     const float mean = d.mean[c], istd = d.invstd[c];
     const float p4 = istd * (q - mean * p2);                     // sum dout*mask*xhat
     float s = 1.f, cb = 0.f, cnt = 0.f, p5 = 0.f;
@@ -575,16 +687,18 @@ __global__ void bnse_bwd_stage2(BnSeBwdArgs a) {
   }
 }
 
-extern "C" int insar_bnse_bwd_coef(const InsarBnSeBwd* d, const float* red, const float* scale, const float* shift,
-                                   float* ws, float* dconv_bias, int32_t training, void* stream) {
+extern "C" int insar_bnse_bwd_coef(const InsarBnSeBwd* d, const float* red, int32_t rows, const float* scale,
+                                   const float* shift, float* ws, float* dconv_bias, int32_t training, void* stream) {
   if (!d || !red || !scale || !shift || !ws || !d->mean || !d->invstd || !d->dgamma || !d->dbeta || !d->k1 || !d->k2)
     INSAR_FAIL(INSAR_E_ARG, "insar_bnse_bwd_coef: null pointer");
   if (d->use_se && (!d->pooled || !d->sq || !d->hid || !d->gate || !d->w1 || !d->w2 || !d->dw1 || !d->dw2 || !d->coefB))
     INSAR_FAIL(INSAR_E_ARG, "insar_bnse_bwd_coef: SE pointers missing");
   if (d->C > 8192 || d->B < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_bnse_bwd_coef: bad shape");
-  BnSeBwdArgs a; a.d = *d; a.red = red; a.scale = scale; a.shift = shift; a.ws = ws; a.dconv_bias = dconv_bias; a.training = training;
+  if (rows < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_bnse_bwd_coef: rows");
+  if (2 * d->C < 256 && (256 % (2 * d->C))) INSAR_FAIL(INSAR_E_SHAPE, "insar_bnse_bwd_coef: C must be a power of two below 128");
+  BnSeBwdArgs a; a.d = *d; a.red = red; a.rows = rows; a.scale = scale; a.shift = shift; a.ws = ws; a.dconv_bias = dconv_bias; a.training = training;
   hipStream_t s = (hipStream_t)stream;
-  size_t lds = (size_t)(d->C + (d->use_se ? d->Cr : 0) + 1) * sizeof(float);
+  size_t lds = (size_t)(3 * d->C + d->Cr + 1 + 256) * sizeof(float);
   hipLaunchKernelGGL(bnse_bwd_stage1, dim3(d->B), dim3(256), lds, s, a);
   int64_t work = d->C;
   if (d->use_se && (int64_t)d->C * d->Cr > work) work = (int64_t)d->C * d->Cr;

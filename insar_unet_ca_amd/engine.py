@@ -113,46 +113,71 @@ class Ctx:
 
 
 class GemmWeight:
-    """GEMM-operand copies ([tap][n][k], compute dtype) of a Conv2d / ConvTranspose2d weight,
-    refreshed when the fp32 master parameter changes (tracked by tensor version + storage)."""
+    """GEMM-operand copies ([tap][n][k], compute dtype) of a Conv2d / ConvTranspose2d weight: the forward
+    form and the transposed / flipped input-gradient form. Refreshed when the fp32 master parameter changes
+    (tensor version + storage); a WeightSet refreshes all weights of a plan in ONE launch."""
 
     def __init__(self, ctx: Ctx, param: torch.nn.Parameter, kind: str):
         self.ctx, self.param, self.kind = ctx, param, kind
-        self._fwd = self._dgrad = None
-        self._fwd_key = self._dgrad_key = None
+        if kind == "conv3":
+            co, ci = param.shape[0], param.shape[1]
+            self._spec = {"fwd": (9, co, ci, 1, ci * 9, 9), "dgrad": (9, ci, co, 1, 9, ci * 9)}
+        else:       # convT (Ci, Co, 2, 2): forward rows n = q*Co + co
+            ci, co = param.shape[0], param.shape[1]
+            self._spec = {"fwd": (4, co, ci, 1, 4, co * 4), "dgrad": (4, ci, co, 1, co * 4, 4)}
+        self._buf = {k: torch.empty(v[:3], dtype=ctx.dtype, device=ctx.device) for k, v in self._spec.items()}
+        self._key = {"fwd": None, "dgrad": None}
 
-    def _key(self):
+    def key(self):
         return (self.param._version, self.param.data_ptr())
 
-    def _prep(self, T, N, K, st, sn, sk) -> torch.Tensor:
-        out = torch.empty((T, N, K), dtype=self.ctx.dtype, device=self.ctx.device)
+    def master(self) -> torch.Tensor:
         w = self.param.detach()
         if w.dtype != torch.float32 or not w.is_contiguous():
-            w = w.float().contiguous()
-        call("insar_weight_prep", ptr(w), ptr(out), self.ctx.code, T, N, K, st, sn, sk, _lib.stream_ptr())
-        return out
+            raise _lib.InsarError("weights must be contiguous float32 parameters")
+        return w
+
+    def _get(self, which: str) -> torch.Tensor:
+        if self._key[which] != self.key():
+            T, N, K, st, sn, sk = self._spec[which]
+            call("insar_weight_prep", ptr(self.master()), ptr(self._buf[which]), self.ctx.code, T, N, K, st, sn, sk,
+                 _lib.stream_ptr())
+            self._key[which] = self.key()
+        return self._buf[which]
 
     def fwd(self) -> torch.Tensor:
-        if self._fwd_key != self._key():
-            if self.kind == "conv3":
-                co, ci = self.param.shape[0], self.param.shape[1]
-                self._fwd = self._prep(9, co, ci, 1, ci * 9, 9)
-            else:  # convT (Ci, Co, 2, 2): rows n = q*Co + co
-                ci, co = self.param.shape[0], self.param.shape[1]
-                self._fwd = self._prep(4, co, ci, 1, 4, co * 4)
-            self._fwd_key = self._key()
-        return self._fwd
+        return self._get("fwd")
 
     def dgrad(self) -> torch.Tensor:
-        if self._dgrad_key != self._key():
-            if self.kind == "conv3":
-                co, ci = self.param.shape[0], self.param.shape[1]
-                self._dgrad = self._prep(9, ci, co, 1, 9, ci * 9)
-            else:
-                ci, co = self.param.shape[0], self.param.shape[1]
-                self._dgrad = self._prep(4, ci, co, 1, co * 4, 4)
-            self._dgrad_key = self._key()
-        return self._dgrad
+        return self._get("dgrad")
+
+
+class WeightSet:
+    """All GemmWeights of a plan: one batched re-layout launch per optimizer step."""
+
+    def __init__(self, ctx: Ctx, weights: List[GemmWeight]):
+        self.ctx, self.weights = ctx, weights
+        self._jobs = None
+        self._ptrs = None
+        self._total = 0
+
+    def refresh(self) -> None:
+        stale = [w for w in self.weights if w._key["fwd"] != w.key() or w._key["dgrad"] != w.key()]
+        if not stale:
+            return
+        ptrs = tuple(w.param.data_ptr() for w in self.weights)
+        if self._jobs is None or ptrs != self._ptrs:
+            rows, tile0 = [], 0
+            for w in self.weights:
+                for which in ("fwd", "dgrad"):
+                    T, N, K, st, sn, sk = w._spec[which]
+                    rows.append([w.master().data_ptr(), w._buf[which].data_ptr(), T, N, K, st, sn, sk, tile0, self.ctx.code])
+                    tile0 += T * ((N + 31) // 32) * ((K + 31) // 32)
+            self._jobs = torch.tensor(rows, dtype=torch.int64).to(self.ctx.device)
+            self._ptrs, self._total = ptrs, tile0
+        call("insar_weight_prep_batch", ptr(self._jobs), self._jobs.shape[0], self._total, _lib.stream_ptr())
+        for w in self.weights:
+            w._key["fwd"] = w._key["dgrad"] = w.key()
 
 
 class KernelTimer:
@@ -301,12 +326,14 @@ class ConvBN:
         else:
             self.stat_rows = call("insar_igemm_num_mtiles", self.M, self.cout)
         self.stats = ctx.f32(self.stat_rows, 2, self.cout)
-        self.sums = ctx.f32(2, self.cout)
+        # BN partial sums: slabs with many rows are folded to <= 64 rows first, bn_finalize folds the rest
+        self.stat_rps = 0 if self.stat_rows <= 128 else max(64, -(-self.stat_rows // 64))
+        self.fold_rows = self.stat_rows if not self.stat_rps else -(-self.stat_rows // self.stat_rps)
+        self.sums = ctx.f32(self.fold_rows, 2, self.cout) if self.stat_rps else self.stats
         self.scale, self.shift = ctx.f32(self.cout), ctx.f32(self.cout)
         self.mean, self.invstd = ctx.f32(self.cout), ctx.f32(self.cout)
         self.k1, self.k2 = ctx.f32(self.cout), ctx.f32(self.cout)
         self.red_part = ctx.f32(B * H, 2, self.cout)
-        self.red = ctx.f32(B, 2, self.cout)
         self.bwd_ws = ctx.f32(B * (3 * self.cout + max(self.cout // 16, 1)))
         self.dy = None            # gradient wrt the raw conv output (allocated on first backward)
         self.w = None if self.small else GemmWeight(ctx, conv.weight, "conv3")
@@ -322,11 +349,11 @@ class ConvBN:
         else:
             _igemm(self.x, self.y, self.w.fwd(), self.cout, self.x.H, self.x.W, 1, _TAPS3, 0,
                    stats=self.stats if training else None)
-        if training:
-            self.ctx.colsum(self.stats, self.sums, 1, self.stat_rows, 2 * self.cout)
+        if training and self.stat_rps:
+            call("insar_colsum_partial", ptr(self.stats), ptr(self.sums), self.stat_rows, 2 * self.cout, self.stat_rps, s)
         bn = self.bn
         d = InsarBnFinalize()
-        d.part, d.count, d.C, d.training = ptr(self.sums), self.M, self.cout, int(training)
+        d.part, d.rows, d.count, d.C, d.training = ptr(self.sums), self.fold_rows, self.M, self.cout, int(training)
         d.conv_bias = ptr(self.conv.bias.detach()) if self.conv.bias is not None else 0
         d.gamma, d.beta = ptr(bn.weight.detach()), ptr(bn.bias.detach())
         d.running_mean, d.running_var = ptr(bn.running_mean), ptr(bn.running_var)
@@ -348,7 +375,6 @@ class ConvBN:
         if self.dy is None:
             self.dy = Act.alloc(B, H, W, self.cout, ctx.dtype, ctx.device)
         call("insar_bnrelu_bwd_reduce", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.red_part), 1, s)
-        ctx.colsum(self.red_part, self.red, B, H, 2 * self.cout)
         d = InsarBnSeBwd()
         d.B, d.H, d.W, d.C = B, H, W, self.cout
         d.Cr = se.cr if se else 1
@@ -363,7 +389,7 @@ class ConvBN:
         d.k1, d.k2 = ptr(self.k1), ptr(self.k2)
         d.accumulate = 0
         dbias = ptr(sink.view(self.conv.bias)) if self.conv.bias is not None else 0
-        call("insar_bnse_bwd_coef", C.byref(d), ptr(self.red), ptr(self.scale), ptr(self.shift), ptr(self.bwd_ws),
+        call("insar_bnse_bwd_coef", C.byref(d), ptr(self.red_part), H, ptr(self.scale), ptr(self.shift), ptr(self.bwd_ws),
              dbias, int(training), s)
         call("insar_bnrelu_bwd_apply", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.mean),
              ptr(self.invstd), ptr(se.gate) if se else 0, ptr(se.coefB) if se else 0, ptr(self.k1), ptr(self.k2),
@@ -452,9 +478,9 @@ class DoubleConvPlan:
         if self.se:
             se, u2 = self.se, self.u2
             call("insar_se_squeeze", u2.y.ref, ptr(u2.scale), ptr(u2.shift), ptr(se.part), 1, s)
-            self.ctx.colsum(se.part, se.pooled, self.x.B, self.x.H, 2 * u2.cout)
             d = InsarSeFwd()
-            d.pooled, d.B, d.H, d.W, d.C, d.Cr = ptr(se.pooled), self.x.B, self.x.H, self.x.W, u2.cout, se.cr
+            d.part, d.rows, d.pooled = ptr(se.part), self.x.H, ptr(se.pooled)
+            d.B, d.H, d.W, d.C, d.Cr = self.x.B, self.x.H, self.x.W, u2.cout, se.cr
             d.scale, d.shift = ptr(u2.scale), ptr(u2.shift)
             d.w1, d.w2 = ptr(se.fc1.weight.detach()), ptr(se.fc2.weight.detach())
             d.sq, d.hid, d.gate = ptr(se.sq), ptr(se.hid), ptr(se.gate)
@@ -632,6 +658,9 @@ class UNetPlan:
         self._closes = {}
         self.busy = False
         self.training = True
+        gws = [b.u1.w for b in self.enc + self.dconv if b.u1.w is not None] + [b.u2.w for b in self.enc + self.dconv]
+        gws += [u.w for u in self.up]
+        self.weightset = WeightSet(ctx, gws)
 
     def bucket_closes(self, min_elems: int):
         if min_elems not in self._closes:
@@ -643,6 +672,7 @@ class UNetPlan:
     def forward(self, x: torch.Tensor, training: bool) -> torch.Tensor:
         s = _lib.stream_ptr
         self.training = training
+        self.weightset.refresh()          # all GEMM-layout weight copies in one launch when the masters moved
         pack_input(x, self.xin)
         for l in range(5):
             self.enc[l].forward(training)

@@ -90,7 +90,7 @@ class _SEPlan:
         self.dx = Act.alloc(B, H, W, Cn, dtype, device)
         self.cr = mod.fc[0].out_features
         self.part = ctx.f32(B * H, 2, Cn)
-        self.pooled, self.red = ctx.f32(B, 2, Cn), ctx.f32(B, 2, Cn)
+        self.pooled, self.red_part = ctx.f32(B, 2, Cn), ctx.f32(B * H, 2, Cn)
         self.sq, self.gate, self.coefB = ctx.f32(B, Cn), ctx.f32(B, Cn), ctx.f32(B, Cn)
         self.hid = ctx.f32(B, self.cr)
         self.ones, self.zeros = ctx.const(1.0, Cn), ctx.const(0.0, Cn)
@@ -103,9 +103,9 @@ class _SEPlan:
         s = _lib.stream_ptr()
         pack_input(x, self.x)
         call("insar_se_squeeze", self.x.ref, ptr(self.ones), ptr(self.zeros), ptr(self.part), 0, s)
-        self.ctx.colsum(self.part, self.pooled, self.B, self.H, 2 * self.C)
         d = InsarSeFwd()
-        d.pooled, d.B, d.H, d.W, d.C, d.Cr = ptr(self.pooled), self.B, self.H, self.W, self.C, self.cr
+        d.part, d.rows, d.pooled = ptr(self.part), self.H, ptr(self.pooled)
+        d.B, d.H, d.W, d.C, d.Cr = self.B, self.H, self.W, self.C, self.cr
         d.scale, d.shift = ptr(self.ones), ptr(self.zeros)
         d.w1, d.w2 = ptr(self.mod.fc[0].weight.detach()), ptr(self.mod.fc[2].weight.detach())
         d.sq, d.hid, d.gate = ptr(self.sq), ptr(self.hid), ptr(self.gate)
@@ -117,8 +117,7 @@ class _SEPlan:
         s = _lib.stream_ptr()
         self.sink.select()
         pack_input(g, self.dout)
-        call("insar_bnrelu_bwd_reduce", self.dout.ref, self.x.ref, ptr(self.ones), ptr(self.zeros), ptr(self.part), 0, s)
-        self.ctx.colsum(self.part, self.red, self.B, self.H, 2 * self.C)
+        call("insar_bnrelu_bwd_reduce", self.dout.ref, self.x.ref, ptr(self.ones), ptr(self.zeros), ptr(self.red_part), 0, s)
         d = InsarBnSeBwd()
         d.B, d.H, d.W, d.C, d.Cr, d.use_se = self.B, self.H, self.W, self.C, self.cr, 1
         d.mean, d.invstd = ptr(self.zeros), ptr(self.ones)
@@ -128,7 +127,7 @@ class _SEPlan:
         d.dw1, d.dw2 = ptr(self.sink.view(w1)), ptr(self.sink.view(w2))
         d.dgamma, d.dbeta = ptr(self.scratch[0]), ptr(self.scratch[1])
         d.coefB, d.k1, d.k2 = ptr(self.coefB), ptr(self.k1), ptr(self.k2)
-        call("insar_bnse_bwd_coef", C.byref(d), ptr(self.red), ptr(self.ones), ptr(self.zeros), ptr(self.ws), 0, 0, s)
+        call("insar_bnse_bwd_coef", C.byref(d), ptr(self.red_part), self.H, ptr(self.ones), ptr(self.zeros), ptr(self.ws), 0, 0, s)
         call("insar_bnrelu_bwd_apply", self.dout.ref, self.x.ref, ptr(self.ones), ptr(self.zeros), ptr(self.zeros),
              ptr(self.ones), ptr(self.gate), ptr(self.coefB), ptr(self.k1), ptr(self.k2), self.dx.ref, 0, s)
         return unpack_output(self.dx), self.sink.view(w1), self.sink.view(w2)

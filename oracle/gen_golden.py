@@ -138,6 +138,44 @@ def main() -> None:
     g3["state_dict_shapes"] = np.array([str(tuple(v.shape)) for v in ref.UNet(2, 2, True).state_dict().values()])
     np.savez_compressed(os.path.join(OUT, "g3_unet.npz"), **g3)
 
+    # ---- G3r / G4r: generic-position (PCG64) weights and inputs: well-conditioned gradients ---------------
+    g3r = {}
+    net = ref.UNet(in_channels=2, num_classes=2, use_se=True)
+    net.load_state_dict(cf.fill_state_dict_random(net.state_dict(), seed=7))
+    net.train(True)
+    x = cf.make_input_random((2, 2, 64, 64), seed=11)
+    tgt = cf.make_target_random((2, 64, 64), seed=13, ignore_frac=0.05)
+    logits = net(x)
+    loss = crit(logits, tgt)
+    loss.backward()
+    summarize("b2_64_train/logits", logits, g3r)
+    g3r["b2_64_train/loss"] = np.array(loss.item())
+    for name, p in net.named_parameters():
+        summarize(f"b2_64_train/grad/{name}", p.grad, g3r)
+    for name, b in net.named_buffers():
+        if not name.endswith("num_batches_tracked"):
+            summarize(f"b2_64_train/buf/{name}", b, g3r)
+    net = ref.UNet(in_channels=2, num_classes=2, use_se=True)
+    net.load_state_dict(cf.fill_state_dict_random(net.state_dict(), seed=7))
+    net.train(True)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    start = {k: v.clone() for k, v in net.state_dict().items()}
+    losses = []
+    for step in range(5):
+        x = cf.make_input_random((2, 2, 64, 64), seed=100 + step)
+        tgt = cf.make_target_random((2, 64, 64), seed=200 + step)
+        opt.zero_grad()
+        loss = crit(net(x), tgt)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    g3r["adam/losses"] = np.array(losses)
+    for k, v in net.state_dict().items():
+        if v.dtype == torch.float32:
+            summarize(f"adam/delta/{k}", v - start[k], g3r)
+            summarize(f"adam/final/{k}", v, g3r)
+    np.savez_compressed(os.path.join(OUT, "g3r_unet_random.npz"), **g3r)
+
     # ---- G4: five Adam steps -------------------------------------------------------------
     g4 = {}
     net = ref.UNet(in_channels=2, num_classes=2, use_se=True)

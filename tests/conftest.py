@@ -11,6 +11,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def pytest_configure(config):
+    # the GPU box shows every host core but grants a 16-core share: cap torch's CPU pool (oracle runs)
+    try:
+        import torch
+        torch.set_num_threads(min(torch.get_num_threads(), 16))
+    except Exception:
+        pass
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 

@@ -209,3 +209,27 @@ def test_dp_mean_of_shard_grads(golden):
                 acc[k] += 0.5 * v.grad
     for k, v in acc.items():
         check_summary(g9, f"mean_grad/{k}", v, 2e-4)
+
+
+def test_unet_random_fixture(golden):
+    """G3r: generic-position (PCG64) weights/inputs, the fixture the gradient parity of the HIP path is pinned on."""
+    g = golden("g3r_unet_random")
+    sd = cf.fill_state_dict_random(orc.state_dict_template(2, 2, True), seed=7)
+    work, leaves = _leafify(sd)
+    x = cf.make_input_random((2, 2, 64, 64), seed=11)
+    tgt = cf.make_target_random((2, 64, 64), seed=13, ignore_frac=0.05)
+    logits = orc.unet_forward(work, x, use_se=True, training=True)
+    loss = orc.cross_entropy(logits, tgt)
+    loss.backward()
+    check_summary(g, "b2_64_train/logits", logits, TOL)
+    assert abs(float(loss.detach()) - float(g["b2_64_train/loss"])) < 1e-5
+    for k, leaf in leaves.items():
+        check_summary(g, f"b2_64_train/grad/{k}", leaf.grad, 2e-4)
+    sd = cf.fill_state_dict_random(orc.state_dict_template(2, 2, True), seed=7)
+    state, losses = {}, []
+    for step in range(5):
+        xs = cf.make_input_random((2, 2, 64, 64), seed=100 + step)
+        ts = cf.make_target_random((2, 64, 64), seed=200 + step)
+        l, _ = orc.train_step(sd, state, xs, ts, use_se=True, lr=1e-4)
+        losses.append(l)
+    np.testing.assert_allclose(losses, g["adam/losses"], rtol=2e-5)

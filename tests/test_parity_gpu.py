@@ -337,14 +337,64 @@ def test_unet_golden_fp32(dev, golden, tag, shape, training):
     assert worst <= 0.2, f"worst gradient-norm deviation {worst:.3e}"
 
 
+def test_unet_fp32_gradients_golden_generic_position(dev, golden):
+    """G3r: on generic-position (PCG64) weights and inputs the gradients of every parameter match the
+    reference's to 5e-3 of the tensor's range (torch's own fp32 vs fp64 gap on this fixture: 3e-4), and a
+    5-step Adam run reproduces the reference's loss curve."""
+    import insar_unet_ca_amd as iu
+    g = golden("g3r_unet_random")
+    net = iu.UNet(2, 2, True)
+    net.load_state_dict(cf.fill_state_dict_random(net.state_dict(), seed=7))
+    net = net.to(dev).train()
+    crit = iu.CrossEntropyLoss(ignore_index=255)
+    x = cf.make_input_random((2, 2, 64, 64), seed=11).to(dev)
+    tgt = cf.make_target_random((2, 64, 64), seed=13, ignore_frac=0.05).to(dev)
+    logits = net(x)
+    loss = crit(logits, tgt)
+    loss.backward()
+    check_summary(g, "b2_64_train/logits", logits, 1e-4)
+    assert abs(float(loss.detach()) - float(g["b2_64_train/loss"])) <= 1e-5
+    for k, p in net.named_parameters():
+        if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
+            assert float(p.grad.abs().max()) == 0.0
+            continue
+        check_summary(g, f"b2_64_train/grad/{k}", p.grad, 5e-3)
+    for k, b in net.named_buffers():
+        if not k.endswith("num_batches_tracked"):
+            check_summary(g, f"b2_64_train/buf/{k}", b, 1e-4)
+    # five Adam steps from the same start
+    net = iu.UNet(2, 2, True)
+    net.load_state_dict(cf.fill_state_dict_random(net.state_dict(), seed=7))
+    net = net.to(dev).train()
+    opt = iu.Adam(net.parameters(), lr=1e-4)
+    losses = []
+    for step in range(5):
+        xs = cf.make_input_random((2, 2, 64, 64), seed=100 + step).to(dev)
+        ts = cf.make_target_random((2, 64, 64), seed=200 + step).to(dev)
+        opt.zero_grad()
+        l = crit(net(xs), ts)
+        l.backward()
+        opt.step()
+        losses.append(float(l.detach()))
+    np.testing.assert_allclose(losses, g["adam/losses"], rtol=1e-3)
+    for k in ("outc.weight", "conv4.double_conv.3.weight", "down4.1.double_conv.3.weight", "up1.weight",
+              "inc.double_conv.6.fc.0.weight", "down2.1.double_conv.4.weight"):
+        nrm = float(g[f"adam/delta/{k}/norm"])
+        delta = net.state_dict()[k].cpu() - cf.fill_state_dict_random(iu.UNet(2, 2, True).state_dict(), seed=7)[k]
+        assert abs(float(delta.norm()) - nrm) / nrm <= 0.05, k
+
+
 def test_unet_fp32_gradients_at_the_float64_noise_floor(dev):
-    """Our fp32 gradient error against a float64 oracle must be no worse than ~torch fp32's own."""
+    """Against a float64 oracle on generic-position data, the HIP fp32 gradient error is of the order of
+    torch-fp32's own error."""
     import insar_unet_ca_amd as iu
     shape = (2, 2, 64, 64)
-    net = _unet(dev).train()
+    net = iu.UNet(2, 2, True)
+    net.load_state_dict(cf.fill_state_dict_random(net.state_dict(), seed=21))
+    net = net.to(dev).train()
     base = OrderedDict((k, v.detach().cpu().clone()) for k, v in net.state_dict().items())
-    x = cf.make_input(shape)
-    tgt = cf.make_target((2, 64, 64), ignore_every=13)
+    x = cf.make_input_random(shape, seed=22)
+    tgt = cf.make_target_random((2, 64, 64), seed=23)
     iu.CrossEntropyLoss(ignore_index=255)(net(x.to(dev)), tgt.to(dev)).backward()
     res = {}
     for dt in (torch.float32, torch.float64):
@@ -364,7 +414,7 @@ def test_unet_fp32_gradients_at_the_float64_noise_floor(dev):
         ref = res[torch.float64][k]
         ours = max(ours, rel_l2(p.grad, ref))
         torch32 = max(torch32, rel_l2(res[torch.float32][k], ref))
-    assert ours <= 3.0 * torch32 + 1e-3, f"HIP fp32 worst rel-L2 {ours:.3e} vs torch fp32 {torch32:.3e}"
+    assert ours <= 5.0 * torch32 + 5e-4, f"HIP fp32 worst rel-L2 {ours:.3e} vs torch fp32 {torch32:.3e}"
 
 
 @pytest.mark.parametrize("use_se,cin", [(False, 2), (True, 1)])
