@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from oracle import closed_form as cf
 from oracle import unet_ca_oracle as orc
-from tests.helpers import check_summary, max_rel, to_np
+from tests.helpers import check_grad_summary, check_summary, max_rel, to_np
 
 pytestmark = pytest.mark.gpu
 
@@ -358,7 +358,7 @@ def test_unet_fp32_gradients_golden_generic_position(dev, golden):
         if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
             assert float(p.grad.abs().max()) == 0.0
             continue
-        check_summary(g, f"b2_64_train/grad/{k}", p.grad, 5e-3)
+        check_grad_summary(g, f"b2_64_train/grad/{k}", p.grad, 5e-3)
     for k, b in net.named_buffers():
         if not k.endswith("num_batches_tracked"):
             check_summary(g, f"b2_64_train/buf/{k}", b, 1e-4)
