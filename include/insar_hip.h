@@ -183,14 +183,14 @@ int insar_bn_relu_apply(const InsarAct* y, const float* scale, const float* shif
                         void* stream);
 
 /* ---- SELayer (:45-72) ----------------------------------------------------------------------------
- * squeeze: per (n, image row, c) partial sums over w of mask and mask*y, mask = (y*scale+shift > 0):
- *   part[B*H][2][C]. */
+ * squeeze: partial sums of mask and mask*y, mask = (y*scale+shift > 0), over `rows_per_part` consecutive
+ *   image rows: part[B][P][2][C], P = ceil(H / rows_per_part). */
 int insar_se_squeeze(const InsarAct* y, const float* scale, const float* shift, float* part,
-                     int32_t relu, void* stream);
+                     int32_t relu, int32_t rows_per_part, void* stream);
 /* excitation: mean -> Linear(C,C/r) -> ReLU -> Linear(C/r,C) -> Sigmoid (two bias-free Linears,
  * :54-59). Saves sq[B][C] (the squeezed mean), hid[B][Cr] (post-ReLU), gate[B][C]. */
 typedef struct InsarSeFwd {
-  const float* part;   /* squeeze slabs [B][rows][2][C] (insar_se_squeeze: rows = H), folded in-kernel */
+  const float* part;   /* squeeze slabs [B][rows][2][C] (insar_se_squeeze: rows = P), folded in-kernel */
   int32_t B, H, W, C, Cr; int32_t rows;
   const float* scale; const float* shift;
   const float* w1; /* (Cr, C) */ const float* w2; /* (C, Cr) */
@@ -200,10 +200,11 @@ typedef struct InsarSeFwd {
 int insar_se_excite(const InsarSeFwd* d, void* stream);
 
 /* ---- backward of [BN -> ReLU -> (SE gate)] ------------------------------------------------------
- * reduce: part[B*H][2][C] = per (n,row) sums over w of  g*mask  and  g*mask*y , g = dout (T).  */
+ * reduce: part[B][P][2][C] = sums over `rows_per_part` image rows of  g*mask  and  g*mask*y , g = dout (T),
+ *   P = ceil(H / rows_per_part).  */
 int insar_bnrelu_bwd_reduce(const InsarAct* dout, const InsarAct* y, const float* scale,
-                            const float* shift, float* part, int32_t relu, void* stream);
-/* coefficient kernels: turn the reduce slabs red[B][rows][2][C] (insar_bnrelu_bwd_reduce: rows = H;
+                            const float* shift, float* part, int32_t relu, int32_t rows_per_part, void* stream);
+/* coefficient kernels: turn the reduce slabs red[B][rows][2][C] (insar_bnrelu_bwd_reduce: rows = P;
  * folded per image in-kernel) into everything the apply pass needs.
  *  with SE:  ds -> MLP backward (dW1, dW2, dsq);  g_eff = (dout*gate + dsq/HW) on the ReLU mask
  *  dgamma/dbeta; coefB[B][C] = dsq/HW and per-channel k1[C] = dbeta/N, k2[C] = dgamma/N (0 in eval):

@@ -408,30 +408,34 @@ extern "C" int insar_bn_relu_apply(const InsarAct* y, const float* scale, const 
 // ---------------------------------------------------------------------------------------------
 template <typename T, bool WITH_G>
 __global__ void row_reduce_kernel(ActView g, ActView y, const float* __restrict__ scale,
-                                  const float* __restrict__ shift, float* __restrict__ part, int relu) {
+                                  const float* __restrict__ shift, float* __restrict__ part, int relu, int rpp) {
   constexpr int CH = Chunk<T>::N;
   __shared__ float red[PW_THREADS][2 * CH + 1];
   const int cpp = y.c_len / CH;
-  const int rows = y.B * y.H;
+  const int ppi = (y.H + rpp - 1) / rpp;          // partials per image
+  const int nparts = y.B * ppi;
   const int total = y.W * cpp;
   const bool inv = (blockDim.x % cpp) == 0;
-  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
-    const int n = r / y.H, h = r - n * y.H;
+  for (int r = blockIdx.x; r < nparts; r += gridDim.x) {
+    const int n = r / ppi, h0 = (r - n * ppi) * rpp;
+    const int h1 = min(y.H, h0 + rpp);
     if (inv) {
       float a0[CH], a1[CH], sc[CH], sh[CH];
       const int cc = threadIdx.x % cpp;
 #pragma unroll
       for (int j = 0; j < CH; ++j) { a0[j] = 0.f; a1[j] = 0.f; sc[j] = scale[cc * CH + j]; sh[j] = shift[cc * CH + j]; }
-      for (int e = threadIdx.x; e < total; e += blockDim.x) {
-        const int w = e / cpp;
-        float f[CH], gg[CH];
-        Chunk<T>::unpack(*chunk_ptr<T>(y, n, h, w, cc), f);
-        if constexpr (WITH_G) Chunk<T>::unpack(*chunk_ptr<T>(g, n, h, w, cc), gg);
+      for (int h = h0; h < h1; ++h) {
+        for (int e = threadIdx.x; e < total; e += blockDim.x) {
+          const int w = e / cpp;
+          float f[CH], gg[CH];
+          Chunk<T>::unpack(*chunk_ptr<T>(y, n, h, w, cc), f);
+          if constexpr (WITH_G) Chunk<T>::unpack(*chunk_ptr<T>(g, n, h, w, cc), gg);
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-          const bool on = !relu || fmaf(f[j], sc[j], sh[j]) > 0.f;
-          const float m = WITH_G ? (on ? gg[j] : 0.f) : (on ? 1.f : 0.f);
-          a0[j] += m; a1[j] = fmaf(m, f[j], a1[j]);
+          for (int j = 0; j < CH; ++j) {
+            const bool on = !relu || fmaf(f[j], sc[j], sh[j]) > 0.f;
+            const float m = WITH_G ? (on ? gg[j] : 0.f) : (on ? 1.f : 0.f);
+            a0[j] += m; a1[j] = fmaf(m, f[j], a1[j]);
+          }
         }
       }
 #pragma unroll
@@ -451,17 +455,18 @@ __global__ void row_reduce_kernel(ActView g, ActView y, const float* __restrict_
       for (int c = threadIdx.x; c < y.c_len; c += blockDim.x) {
         float s0 = 0.f, s1 = 0.f;
         const float sc = scale[c], sh = shift[c];
-        for (int w = 0; w < y.W; ++w) {
-          const T* py = (const T*)(y.base + (y.elem_offset(n, h, w) + c) * (int64_t)sizeof(T));
-          float f, gg = 1.f;
-          if constexpr (sizeof(T) == 2) f = bf16_to_f32(*(const uint16_t*)py); else f = *(const float*)py;
-          if constexpr (WITH_G) {
-            const T* pg = (const T*)(g.base + (g.elem_offset(n, h, w) + c) * (int64_t)sizeof(T));
-            if constexpr (sizeof(T) == 2) gg = bf16_to_f32(*(const uint16_t*)pg); else gg = *(const float*)pg;
+        for (int h = h0; h < h1; ++h)
+          for (int w = 0; w < y.W; ++w) {
+            const T* py = (const T*)(y.base + (y.elem_offset(n, h, w) + c) * (int64_t)sizeof(T));
+            float f, gg = 1.f;
+            if constexpr (sizeof(T) == 2) f = bf16_to_f32(*(const uint16_t*)py); else f = *(const float*)py;
+            if constexpr (WITH_G) {
+              const T* pg = (const T*)(g.base + (g.elem_offset(n, h, w) + c) * (int64_t)sizeof(T));
+              if constexpr (sizeof(T) == 2) gg = bf16_to_f32(*(const uint16_t*)pg); else gg = *(const float*)pg;
+            }
+            const float m = (!relu || fmaf(f, sc, sh) > 0.f) ? gg : 0.f;
+            s0 += m; s1 = fmaf(m, f, s1);
           }
-          const float m = (!relu || fmaf(f, sc, sh) > 0.f) ? gg : 0.f;
-          s0 += m; s1 = fmaf(m, f, s1);
-        }
         part[((int64_t)r * 2 + 0) * y.c_len + c] = s0;
         part[((int64_t)r * 2 + 1) * y.c_len + c] = s1;
       }
@@ -470,52 +475,61 @@ __global__ void row_reduce_kernel(ActView g, ActView y, const float* __restrict_
 }
 
 extern "C" int insar_se_squeeze(const InsarAct* y, const float* scale, const float* shift, float* part, int32_t relu,
-                                void* stream) {
+                                int32_t rows_per_part, void* stream) {
   int rc;
   if ((rc = insar_check_act(y, "insar_se_squeeze", "y"))) return rc;
   if (!scale || !shift || !part) INSAR_FAIL(INSAR_E_ARG, "insar_se_squeeze: null pointer");
-  int grid = insar_grid_cap((int64_t)y->B * y->H);
+  if (rows_per_part < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_se_squeeze: rows_per_part");
+  const int rpp = rows_per_part;
+  int grid = insar_grid_cap((int64_t)y->B * ((y->H + rpp - 1) / rpp));
   hipStream_t s = (hipStream_t)stream;
   ActView v = make_view(*y);
-  if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, false>), dim3(grid), dim3(PW_THREADS), 0, s, v, v, scale, shift, part, relu);
-  else hipLaunchKernelGGL((row_reduce_kernel<float, false>), dim3(grid), dim3(PW_THREADS), 0, s, v, v, scale, shift, part, relu);
+  if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, false>), dim3(grid), dim3(PW_THREADS), 0, s, v, v, scale, shift, part, relu, rpp);
+  else hipLaunchKernelGGL((row_reduce_kernel<float, false>), dim3(grid), dim3(PW_THREADS), 0, s, v, v, scale, shift, part, relu, rpp);
   INSAR_CHECK_LAUNCH("insar_se_squeeze");
   return INSAR_OK;
 }
 
 extern "C" int insar_bnrelu_bwd_reduce(const InsarAct* dout, const InsarAct* y, const float* scale, const float* shift,
-                                       float* part, int32_t relu, void* stream) {
+                                       float* part, int32_t relu, int32_t rows_per_part, void* stream) {
   int rc;
   if ((rc = insar_check_act(y, "insar_bnrelu_bwd_reduce", "y"))) return rc;
   if ((rc = insar_check_act(dout, "insar_bnrelu_bwd_reduce", "dout"))) return rc;
   if ((rc = check_same_grid(y, dout, "insar_bnrelu_bwd_reduce"))) return rc;
   if (!scale || !shift || !part) INSAR_FAIL(INSAR_E_ARG, "insar_bnrelu_bwd_reduce: null pointer");
-  int grid = insar_grid_cap((int64_t)y->B * y->H);
+  if (rows_per_part < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_bnrelu_bwd_reduce: rows_per_part");
+  const int rpp = rows_per_part;
+  int grid = insar_grid_cap((int64_t)y->B * ((y->H + rpp - 1) / rpp));
   hipStream_t s = (hipStream_t)stream;
-  if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, true>), dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, part, relu);
-  else hipLaunchKernelGGL((row_reduce_kernel<float, true>), dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, part, relu);
+  if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, true>), dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, part, relu, rpp);
+  else hipLaunchKernelGGL((row_reduce_kernel<float, true>), dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, part, relu, rpp);
   INSAR_CHECK_LAUNCH("insar_bnrelu_bwd_reduce");
   return INSAR_OK;
 }
 
 // Sum `rows` rows of a [rows][cols] fp32 slab into out[cols] (LDS), all threads of the block cooperating:
 // columns across lanes (coalesced), row lanes when cols < blockDim. `scratch` needs blockDim floats.
+__device__ __forceinline__ float strided_sum4(const float* __restrict__ p, int first, int rows, int step, int64_t ld) {
+  // four independent partial sums so that the loads of one thread overlap (fixed order => deterministic)
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int r = first;
+  for (; r + 3 * step < rows; r += 4 * step) {
+    a0 += p[(int64_t)r * ld]; a1 += p[(int64_t)(r + step) * ld];
+    a2 += p[(int64_t)(r + 2 * step) * ld]; a3 += p[(int64_t)(r + 3 * step) * ld];
+  }
+  for (; r < rows; r += step) a0 += p[(int64_t)r * ld];
+  return (a0 + a1) + (a2 + a3);
+}
+
 __device__ __forceinline__ void block_colsum(const float* __restrict__ slab, int rows, int cols, float* out, float* scratch) {
   const int nt = blockDim.x;
   if (cols >= nt) {
-    for (int c = threadIdx.x; c < cols; c += nt) {
-      float a = 0.f;
-      for (int r = 0; r < rows; ++r) a += slab[(int64_t)r * cols + c];
-      out[c] = a;
-    }
+    for (int c = threadIdx.x; c < cols; c += nt) out[c] = strided_sum4(slab + c, 0, rows, 1, cols);
     __syncthreads();
   } else {
     const int lanes = nt / cols;                       // row lanes (cols is a power of two <= nt)
     const int c = threadIdx.x % cols, rl = threadIdx.x / cols;
-    float a = 0.f;
-    if (rl < lanes)
-      for (int r = rl; r < rows; r += lanes) a += slab[(int64_t)r * cols + c];
-    scratch[threadIdx.x] = a;
+    scratch[threadIdx.x] = rl < lanes ? strided_sum4(slab + c, rl, rows, lanes, cols) : 0.f;
     __syncthreads();
     if (threadIdx.x < cols) {
       float t = 0.f;

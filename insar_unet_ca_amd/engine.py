@@ -250,6 +250,12 @@ def _launch_wgrad(d: InsarWgrad, M: int, cin: int, cout: int, ntaps: int, code: 
     call("insar_wgrad", C.byref(d), _lib.stream_ptr())
 
 
+def _rows_per_part(B: int, H: int) -> int:
+    """Image rows folded into one partial-sum row by the row reductions: keep >= ~1024 work-groups in flight
+    but hand the per-image fold (one work-group per image) at most 64 rows."""
+    return max(1, (B * H) // 1024, -(-H // 64))
+
+
 def _wgrad_nsplit(tiles: int, ksteps: int, slab_floats: int = 0, tm: int = 128, tn: int = 128, esize: int = 2) -> int:
     """Split-K factor for the weight-gradient GEMM. The grid is tiles*nsplit work-groups at two per CU
     (512 slots): pick the factor that minimises an estimate of
@@ -333,7 +339,9 @@ class ConvBN:
         self.scale, self.shift = ctx.f32(self.cout), ctx.f32(self.cout)
         self.mean, self.invstd = ctx.f32(self.cout), ctx.f32(self.cout)
         self.k1, self.k2 = ctx.f32(self.cout), ctx.f32(self.cout)
-        self.red_part = ctx.f32(B * H, 2, self.cout)
+        self.red_rpp = _rows_per_part(B, H)
+        self.red_rows = -(-H // self.red_rpp)
+        self.red_part = ctx.f32(B * self.red_rows, 2, self.cout)
         self.bwd_ws = ctx.f32(B * (3 * self.cout + max(self.cout // 16, 1)))
         self.dy = None            # gradient wrt the raw conv output (allocated on first backward)
         self.w = None if self.small else GemmWeight(ctx, conv.weight, "conv3")
@@ -374,7 +382,7 @@ class ConvBN:
         B, H, W = self.x.B, self.x.H, self.x.W
         if self.dy is None:
             self.dy = Act.alloc(B, H, W, self.cout, ctx.dtype, ctx.device)
-        call("insar_bnrelu_bwd_reduce", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.red_part), 1, s)
+        call("insar_bnrelu_bwd_reduce", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.red_part), 1, self.red_rpp, s)
         d = InsarBnSeBwd()
         d.B, d.H, d.W, d.C = B, H, W, self.cout
         d.Cr = se.cr if se else 1
@@ -389,7 +397,7 @@ class ConvBN:
         d.k1, d.k2 = ptr(self.k1), ptr(self.k2)
         d.accumulate = 0
         dbias = ptr(sink.view(self.conv.bias)) if self.conv.bias is not None else 0
-        call("insar_bnse_bwd_coef", C.byref(d), ptr(self.red_part), H, ptr(self.scale), ptr(self.shift), ptr(self.bwd_ws),
+        call("insar_bnse_bwd_coef", C.byref(d), ptr(self.red_part), self.red_rows, ptr(self.scale), ptr(self.shift), ptr(self.bwd_ws),
              dbias, int(training), s)
         call("insar_bnrelu_bwd_apply", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.mean),
              ptr(self.invstd), ptr(se.gate) if se else 0, ptr(se.coefB) if se else 0, ptr(self.k1), ptr(self.k2),
@@ -442,7 +450,9 @@ class SEState:
     def __init__(self, ctx: Ctx, se_module, B: int, H: int, Cn: int):
         self.fc1, self.fc2 = se_module.fc[0], se_module.fc[2]
         self.cr = self.fc1.out_features
-        self.part = ctx.f32(B * H, 2, Cn)
+        self.rpp = _rows_per_part(B, H)
+        self.rows = -(-H // self.rpp)
+        self.part = ctx.f32(B * self.rows, 2, Cn)
         self.pooled = ctx.f32(B, 2, Cn)
         self.sq, self.gate, self.coefB = ctx.f32(B, Cn), ctx.f32(B, Cn), ctx.f32(B, Cn)
         self.hid = ctx.f32(B, self.cr)
@@ -477,9 +487,9 @@ class DoubleConvPlan:
         self.u2.forward_conv(training)
         if self.se:
             se, u2 = self.se, self.u2
-            call("insar_se_squeeze", u2.y.ref, ptr(u2.scale), ptr(u2.shift), ptr(se.part), 1, s)
+            call("insar_se_squeeze", u2.y.ref, ptr(u2.scale), ptr(u2.shift), ptr(se.part), 1, se.rpp, s)
             d = InsarSeFwd()
-            d.part, d.rows, d.pooled = ptr(se.part), self.x.H, ptr(se.pooled)
+            d.part, d.rows, d.pooled = ptr(se.part), se.rows, ptr(se.pooled)
             d.B, d.H, d.W, d.C, d.Cr = self.x.B, self.x.H, self.x.W, u2.cout, se.cr
             d.scale, d.shift = ptr(u2.scale), ptr(u2.shift)
             d.w1, d.w2 = ptr(se.fc1.weight.detach()), ptr(se.fc2.weight.detach())
@@ -505,7 +515,9 @@ class UpPlan:
         if self.cin % 64 or self.cout % 64:
             raise _lib.InsarError(f"{name}: channels must be multiples of 64 on the HIP path")
         self.w = GemmWeight(ctx, mod.weight, "convT")
-        self.bias_part = ctx.f32(out.B * out.H, 2, self.cout)
+        self.bias_rpp = _rows_per_part(out.B, out.H)
+        self.bias_rows = out.B * -(-out.H // self.bias_rpp)
+        self.bias_part = ctx.f32(self.bias_rows, 2, self.cout)
 
     def params(self):
         return [self.mod.weight, self.mod.bias]
@@ -520,9 +532,9 @@ class UpPlan:
         x, B, h, w = self.x, self.x.B, self.x.H, self.x.W
         if self.mod.bias is not None:     # dbias = sum over pixels of dout (mask-free row reduction)
             call("insar_bnrelu_bwd_reduce", dout.ref, dout.ref, ptr(ctx.const(0.0, self.cout)),
-                 ptr(ctx.const(1.0, self.cout)), ptr(self.bias_part), 0, s)
+                 ptr(ctx.const(1.0, self.cout)), ptr(self.bias_part), 0, self.bias_rpp, s)
             tmp = ctx.f32(2, self.cout)
-            ctx.colsum(self.bias_part, tmp, 1, dout.B * dout.H, 2 * self.cout)
+            ctx.colsum(self.bias_part, tmp, 1, self.bias_rows, 2 * self.cout)
             sink.view(self.mod.bias).copy_(tmp[0])
         tabx = ctx.pixel_table(B, h, w, 1, h, w, 0)
         tabdy = ctx.pixel_table(B, h, w, 2, dout.H, dout.W, 0)

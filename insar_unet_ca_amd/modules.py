@@ -17,6 +17,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import InsarBnSeBwd, InsarSeFwd, call, ptr
+from . import engine
 from .engine import Act, Ctx, DoubleConvPlan, GradSink, UNetPlan, pack_input, unpack_output
 
 
@@ -89,8 +90,10 @@ class _SEPlan:
         self.dout = Act.alloc(B, H, W, Cn, dtype, device)
         self.dx = Act.alloc(B, H, W, Cn, dtype, device)
         self.cr = mod.fc[0].out_features
-        self.part = ctx.f32(B * H, 2, Cn)
-        self.pooled, self.red_part = ctx.f32(B, 2, Cn), ctx.f32(B * H, 2, Cn)
+        self.rpp = engine._rows_per_part(B, H)
+        self.rows = -(-H // self.rpp)
+        self.part = ctx.f32(B * self.rows, 2, Cn)
+        self.pooled, self.red_part = ctx.f32(B, 2, Cn), ctx.f32(B * self.rows, 2, Cn)
         self.sq, self.gate, self.coefB = ctx.f32(B, Cn), ctx.f32(B, Cn), ctx.f32(B, Cn)
         self.hid = ctx.f32(B, self.cr)
         self.ones, self.zeros = ctx.const(1.0, Cn), ctx.const(0.0, Cn)
@@ -102,9 +105,9 @@ class _SEPlan:
     def forward(self, x):
         s = _lib.stream_ptr()
         pack_input(x, self.x)
-        call("insar_se_squeeze", self.x.ref, ptr(self.ones), ptr(self.zeros), ptr(self.part), 0, s)
+        call("insar_se_squeeze", self.x.ref, ptr(self.ones), ptr(self.zeros), ptr(self.part), 0, self.rpp, s)
         d = InsarSeFwd()
-        d.part, d.rows, d.pooled = ptr(self.part), self.H, ptr(self.pooled)
+        d.part, d.rows, d.pooled = ptr(self.part), self.rows, ptr(self.pooled)
         d.B, d.H, d.W, d.C, d.Cr = self.B, self.H, self.W, self.C, self.cr
         d.scale, d.shift = ptr(self.ones), ptr(self.zeros)
         d.w1, d.w2 = ptr(self.mod.fc[0].weight.detach()), ptr(self.mod.fc[2].weight.detach())
@@ -117,7 +120,7 @@ class _SEPlan:
         s = _lib.stream_ptr()
         self.sink.select()
         pack_input(g, self.dout)
-        call("insar_bnrelu_bwd_reduce", self.dout.ref, self.x.ref, ptr(self.ones), ptr(self.zeros), ptr(self.red_part), 0, s)
+        call("insar_bnrelu_bwd_reduce", self.dout.ref, self.x.ref, ptr(self.ones), ptr(self.zeros), ptr(self.red_part), 0, self.rpp, s)
         d = InsarBnSeBwd()
         d.B, d.H, d.W, d.C, d.Cr, d.use_se = self.B, self.H, self.W, self.C, self.cr, 1
         d.mean, d.invstd = ptr(self.zeros), ptr(self.ones)
@@ -127,7 +130,7 @@ class _SEPlan:
         d.dw1, d.dw2 = ptr(self.sink.view(w1)), ptr(self.sink.view(w2))
         d.dgamma, d.dbeta = ptr(self.scratch[0]), ptr(self.scratch[1])
         d.coefB, d.k1, d.k2 = ptr(self.coefB), ptr(self.k1), ptr(self.k2)
-        call("insar_bnse_bwd_coef", C.byref(d), ptr(self.red_part), self.H, ptr(self.ones), ptr(self.zeros), ptr(self.ws), 0, 0, s)
+        call("insar_bnse_bwd_coef", C.byref(d), ptr(self.red_part), self.rows, ptr(self.ones), ptr(self.zeros), ptr(self.ws), 0, 0, s)
         call("insar_bnrelu_bwd_apply", self.dout.ref, self.x.ref, ptr(self.ones), ptr(self.zeros), ptr(self.zeros),
              ptr(self.ones), ptr(self.gate), ptr(self.coefB), ptr(self.k1), ptr(self.k2), self.dx.ref, 0, s)
         return unpack_output(self.dx), self.sink.view(w1), self.sink.view(w2)

@@ -77,11 +77,20 @@ def is_param(name: str) -> bool:
 # --------------------------------------------------------------------------------------
 # blocks
 # --------------------------------------------------------------------------------------
-def se_layer(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+# Test hook. The network has three kinds of discontinuous decisions: the ReLU after each BatchNorm, the ReLU
+# inside the SE bottleneck and the arg-max of each 2x2 max-pool. When DECISION_HOOK is set to
+# f(kind, name, tensor) -> tensor  (kind in "relu" | "se_relu" | "pool") it replaces that operation; the
+# gradient parity tests use it to evaluate the oracle's backward under GIVEN decisions (y * mask, gather at
+# given indices), which removes every discontinuity from the comparison (tests/test_parity_gpu.py).
+DECISION_HOOK = None
+
+
+def se_layer(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, name: str = "") -> torch.Tensor:
     """SELayer.forward, Unet-ChannalAttention.py:61-72 (two bias-free Linears, :54-59)."""
     b, c = x.shape[0], x.shape[1]
     squeeze = x.mean(dim=(2, 3))                        # AdaptiveAvgPool2d(1).view(b,c)  :65
-    hidden = torch.relu(squeeze @ w1.t())               # Linear(C, C/16) + ReLU          :55-56
+    pre = squeeze @ w1.t()                              # Linear(C, C/16)                 :55
+    hidden = DECISION_HOOK("se_relu", name, pre) if DECISION_HOOK is not None else torch.relu(pre)   # :56
     gate = torch.sigmoid(hidden @ w2.t())               # Linear(C/16, C) + Sigmoid       :57-58
     return x * gate.view(b, c, 1, 1)                    # :72
 
@@ -95,6 +104,8 @@ def _bn_relu(x, sd, prefix, training, eps, momentum):
         training=training, momentum=momentum, eps=eps)
     if training:
         sd[f"{prefix}.num_batches_tracked"] += 1
+    if DECISION_HOOK is not None:
+        return DECISION_HOOK("relu", prefix, y)
     return torch.relu(y)
 
 
@@ -107,7 +118,7 @@ def double_conv(x, sd, prefix: str, use_se: bool, training: bool,
     x = F.conv2d(x, sd[f"{p}.3.weight"], sd[f"{p}.3.bias"], padding=1)
     x = _bn_relu(x, sd, f"{p}.4", training, eps, momentum)
     if use_se:
-        x = se_layer(x, sd[f"{p}.6.fc.0.weight"], sd[f"{p}.6.fc.2.weight"])
+        x = se_layer(x, sd[f"{p}.6.fc.0.weight"], sd[f"{p}.6.fc.2.weight"], f"{p}.6")
     return x
 
 
@@ -120,7 +131,7 @@ def unet_forward(sd, x: torch.Tensor, use_se: bool = True, training: bool = True
     h = double_conv(x, sd, "inc", use_se, training)
     for i in range(1, 5):
         skips.append(h)
-        h = F.max_pool2d(h, 2)                                         # :106-109
+        h = DECISION_HOOK("pool", f"down{i}.0", h) if DECISION_HOOK is not None else F.max_pool2d(h, 2)   # :106-109
         h = double_conv(h, sd, f"down{i}.1", use_se, training)
     for i in range(1, 5):
         h = F.conv_transpose2d(h, sd[f"up{i}.weight"], sd[f"up{i}.bias"], stride=2)   # :112..
