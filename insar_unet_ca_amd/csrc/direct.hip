@@ -16,24 +16,45 @@ __device__ __forceinline__ float load_elem(const char* p) {
 // ---------------------------------------------------------------------------------------------
 // first-layer conv forward: thread -> (pixel w, 16-byte chunk of output channels)
 // stats: part[(n*H + h)][2][Co] partial sums of the stored output over the row.
+// The thread's 9*CI*CH weights stay in registers for the whole grid-stride loop; the CI input channels
+// of a tap are one 4- or 8-byte load when CI*sizeof(T) allows it.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void conv3x3_small_fwd_kernel(ActView x, const float* __restrict__ wt, ActView y, float* __restrict__ part) {
-  constexpr int CH = Chunk<T>::N;
-  extern __shared__ float sm[];
-  const int Ci = x.c_len, Co = y.c_len;
-  float* sw = sm;                                   // [9*Ci][Co]
-  float* red = sm + 9 * Ci * Co;                    // [DR_THREADS][2*CH+1]
-  for (int i = threadIdx.x; i < 9 * Ci * Co; i += blockDim.x) {
-    const int k = i / Co, co = i - k * Co;         // k = tap*Ci + ci
-    const int tap = k / Ci, ci = k - tap * Ci;
-    sw[i] = wt[((int64_t)co * Ci + ci) * 9 + tap];
+template <typename T, int CI>
+__device__ __forceinline__ void load_pixel(const char* p, float (&v)[CI]) {
+  if constexpr (sizeof(T) == 2 && CI == 2) {
+    const uint32_t u = *(const uint32_t*)p;
+    v[0] = bf16_to_f32((uint16_t)(u & 0xffffu)); v[1] = bf16_to_f32((uint16_t)(u >> 16));
+  } else if constexpr (sizeof(T) == 2 && CI == 4) {
+    const uint2 u = *(const uint2*)p;
+    v[0] = bf16_to_f32((uint16_t)(u.x & 0xffffu)); v[1] = bf16_to_f32((uint16_t)(u.x >> 16));
+    v[2] = bf16_to_f32((uint16_t)(u.y & 0xffffu)); v[3] = bf16_to_f32((uint16_t)(u.y >> 16));
+  } else if constexpr (sizeof(T) == 4 && CI == 2) {
+    const float2 u = *(const float2*)p; v[0] = u.x; v[1] = u.y;
+  } else if constexpr (sizeof(T) == 4 && CI == 4) {
+    const float4 u = *(const float4*)p; v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+  } else {
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) v[ci] = load_elem<T>(p + ci * sizeof(T));
   }
-  __syncthreads();
+}
+
+template <typename T, int CI>
+__global__ void __launch_bounds__(DR_THREADS)
+conv3x3_small_fwd_kernel(ActView x, const float* __restrict__ wt, ActView y, float* __restrict__ part) {
+  constexpr int CH = Chunk<T>::N;
+  __shared__ float red[DR_THREADS * (2 * CH + 1)];
+  const int Co = y.c_len;
   const int cpp = Co / CH;
   const int rows = y.B * y.H;
   const int total = y.W * cpp;
   const int cc = threadIdx.x % cpp;                 // host guarantees blockDim % cpp == 0
+  float wr[9][CI][CH];                              // torch layout (Co, Ci, 3, 3)
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+      for (int j = 0; j < CH; ++j) wr[tap][ci][j] = wt[((int64_t)(cc * CH + j) * CI + ci) * 9 + tap];
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const int n = r / y.H, h = r - n * y.H;
     float s1[CH], s2[CH];
@@ -44,16 +65,15 @@ __global__ void conv3x3_small_fwd_kernel(ActView x, const float* __restrict__ wt
       float acc[CH];
 #pragma unroll
       for (int j = 0; j < CH; ++j) acc[j] = 0.f;
+      const char* p0 = x.base + x.elem_offset(n, h - 1, w - 1) * (int64_t)sizeof(T);
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        const char* px = x.base + x.elem_offset(n, h + dy, w + dx) * (int64_t)sizeof(T);
-        for (int ci = 0; ci < Ci; ++ci) {
-          const float xv = load_elem<T>(px + ci * sizeof(T));
-          const float* wrow = sw + (tap * Ci + ci) * Co + cc * CH;
+        float xv[CI];
+        load_pixel<T, CI>(p0 + ((int64_t)(tap / 3) * (x.W + 2) + (tap % 3)) * x.C * (int64_t)sizeof(T), xv);
 #pragma unroll
-          for (int j = 0; j < CH; ++j) acc[j] = fmaf(xv, wrow[j], acc[j]);
-        }
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+          for (int j = 0; j < CH; ++j) acc[j] = fmaf(xv[ci], wr[tap][ci][j], acc[j]);
       }
       const uint4 packed = Chunk<T>::pack(acc);
       float f[CH];
@@ -94,12 +114,20 @@ extern "C" int insar_conv3x3_small_fwd(const InsarAct* x, const float* w, const 
   int rc;
   if ((rc = check_small(x, y, "insar_conv3x3_small_fwd"))) return rc;
   if (!w) INSAR_FAIL(INSAR_E_ARG, "insar_conv3x3_small_fwd: null weights");
-  const int ch = y->dtype == INSAR_BF16 ? 8 : 4;
-  size_t lds = (size_t)(9 * x->c_len * y->c_len + DR_THREADS * (2 * ch + 1)) * sizeof(float);
+  if ((x->c_len == 2 || x->c_len == 4) && (x->C % x->c_len || x->c_off % x->c_len))
+    INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_small_fwd: input slice must be aligned to its %d channels", x->c_len);
   int grid = insar_grid_cap((int64_t)y->B * y->H);
   hipStream_t s = (hipStream_t)stream;
-  if (y->dtype == INSAR_BF16) hipLaunchKernelGGL(conv3x3_small_fwd_kernel<bf16_t>, dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), w, make_view(*y), stats);
-  else hipLaunchKernelGGL(conv3x3_small_fwd_kernel<float>, dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), w, make_view(*y), stats);
+  const ActView xv = make_view(*x), yv = make_view(*y);
+#define SMALL_FWD(T, CI) hipLaunchKernelGGL((conv3x3_small_fwd_kernel<T, CI>), dim3(grid), dim3(DR_THREADS), 0, s, xv, w, yv, stats)
+  if (y->dtype == INSAR_BF16) {
+    switch (x->c_len) { case 1: SMALL_FWD(bf16_t, 1); break; case 2: SMALL_FWD(bf16_t, 2); break;
+                        case 3: SMALL_FWD(bf16_t, 3); break; default: SMALL_FWD(bf16_t, 4); break; }
+  } else {
+    switch (x->c_len) { case 1: SMALL_FWD(float, 1); break; case 2: SMALL_FWD(float, 2); break;
+                        case 3: SMALL_FWD(float, 3); break; default: SMALL_FWD(float, 4); break; }
+  }
+#undef SMALL_FWD
   INSAR_CHECK_LAUNCH("insar_conv3x3_small_fwd");
   return INSAR_OK;
 }

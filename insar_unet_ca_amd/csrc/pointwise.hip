@@ -300,18 +300,28 @@ extern "C" int insar_colsum_partial(const float* part, float* out, int64_t rows,
 // sums[0][c] = sum y_raw, sums[1][c] = sum y_raw^2 over `count` pixels (y_raw = conv w/o bias).
 // ---------------------------------------------------------------------------------------------
 __global__ void bn_finalize_kernel(InsarBnFinalize d) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && d.training && d.num_batches_tracked) *d.num_batches_tracked += 1;
-  if (c >= d.C) return;
+  // 64 channels per block, 4 row lanes per channel (threadIdx = lane*64 + channel)
+  __shared__ double fold[2][4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  if (c == 0 && rl == 0 && d.training && d.num_batches_tracked) *d.num_batches_tracked += 1;
+  if (d.training) {
+    double s1 = 0.0, s2 = 0.0;
+    if (c < d.C)
+      for (int64_t r = rl; r < d.rows; r += 4) {     // fold the remaining partial rows: [rows][2][C]
+        s1 += (double)d.part[(r * 2 + 0) * d.C + c];
+        s2 += (double)d.part[(r * 2 + 1) * d.C + c];
+      }
+    fold[0][rl][cl] = s1; fold[1][rl][cl] = s2;
+    __syncthreads();
+  }
+  if (rl != 0 || c >= d.C) return;
   const float cb = d.conv_bias ? d.conv_bias[c] : 0.f;
   float mean_raw, invstd;
   if (d.training) {
     const double n = (double)d.count;
-    double s1 = 0.0, s2 = 0.0;
-    for (int64_t r = 0; r < d.rows; ++r) {          // fold the (few) remaining partial rows: [rows][2][C]
-      s1 += (double)d.part[(r * 2 + 0) * d.C + c];
-      s2 += (double)d.part[(r * 2 + 1) * d.C + c];
-    }
+    const double s1 = (fold[0][0][cl] + fold[0][1][cl]) + (fold[0][2][cl] + fold[0][3][cl]);
+    const double s2 = (fold[1][0][cl] + fold[1][1][cl]) + (fold[1][2][cl] + fold[1][3][cl]);
     const double m = s1 / n;
     double var = s2 / n - m * m;
     if (var < 0) var = 0;
@@ -340,7 +350,7 @@ extern "C" int insar_bn_finalize(const InsarBnFinalize* d, void* stream) {
   if (d->training && (!d->part || d->count < 1 || d->rows < 1 || d->rows > 4096))
     INSAR_FAIL(INSAR_E_ARG, "insar_bn_finalize: training needs 1..4096 rows of partial sums");
   if (!d->training && (!d->running_mean || !d->running_var)) INSAR_FAIL(INSAR_E_ARG, "insar_bn_finalize: eval needs running stats");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->C + 63) / 64), dim3(64), 0, (hipStream_t)stream, *d);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->C + 63) / 64), dim3(256), 0, (hipStream_t)stream, *d);
   INSAR_CHECK_LAUNCH("insar_bn_finalize");
   return INSAR_OK;
 }
@@ -348,6 +358,8 @@ extern "C" int insar_bn_finalize(const InsarBnFinalize* d, void* stream) {
 // ---------------------------------------------------------------------------------------------
 // z = relu(y*scale + shift) * gate[n][c]   (:82-83 / :85-86 and the SE scale :72)
 // ---------------------------------------------------------------------------------------------
+#define PW_UNROLL 4   // 16-byte chunks in flight per thread and operand (HBM latency hiding)
+
 template <typename T>
 __global__ void bn_relu_apply_kernel(ActView y, const float* __restrict__ scale, const float* __restrict__ shift,
                                      const float* __restrict__ gate, ActView dst, int relu) {
@@ -357,18 +369,45 @@ __global__ void bn_relu_apply_kernel(ActView y, const float* __restrict__ scale,
   const int total = y.W * cpp;
   const bool inv = (blockDim.x % cpp) == 0;
   float sc[CH], sh[CH], gt[CH];
-  int cc_loaded = -1, n_loaded = -1;
+  if (inv) {
+    // the thread's channel chunk never changes: constants hoisted, PW_UNROLL loads in flight
+    const int cc = threadIdx.x % cpp, wstep = blockDim.x / cpp;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { sc[j] = scale[cc * CH + j]; sh[j] = shift[cc * CH + j]; gt[j] = 1.f; }
+    int n_loaded = -1;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+      const int n = r / y.H, h = r - n * y.H;
+      if (gate && n != n_loaded) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) gt[j] = gate[(int64_t)n * y.c_len + cc * CH + j];
+        n_loaded = n;
+      }
+      for (int w0 = threadIdx.x / cpp; w0 < y.W; w0 += PW_UNROLL * wstep) {
+        uint4 v[PW_UNROLL];
+#pragma unroll
+        for (int u = 0; u < PW_UNROLL; ++u)
+          if (w0 + u * wstep < y.W) v[u] = *chunk_ptr<T>(y, n, h, w0 + u * wstep, cc);
+#pragma unroll
+        for (int u = 0; u < PW_UNROLL; ++u)
+          if (w0 + u * wstep < y.W) {
+            float f[CH];
+            Chunk<T>::unpack(v[u], f);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { const float z = fmaf(f[j], sc[j], sh[j]); f[j] = (relu ? fmaxf(z, 0.f) : z) * gt[j]; }
+            *chunk_ptr_w<T>(dst, n, h, w0 + u * wstep, cc) = Chunk<T>::pack(f);
+          }
+      }
+    }
+    return;
+  }
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const int n = r / y.H, h = r - n * y.H;
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
       const int w = e / cpp, cc = e - w * cpp;
-      if (!inv || cc != cc_loaded || n != n_loaded) {
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-          sc[j] = scale[cc * CH + j]; sh[j] = shift[cc * CH + j];
-          gt[j] = gate ? gate[(int64_t)n * y.c_len + cc * CH + j] : 1.f;
-        }
-        cc_loaded = cc; n_loaded = n;
+      for (int j = 0; j < CH; ++j) {
+        sc[j] = scale[cc * CH + j]; sh[j] = shift[cc * CH + j];
+        gt[j] = gate ? gate[(int64_t)n * y.c_len + cc * CH + j] : 1.f;
       }
       float f[CH];
       Chunk<T>::unpack(*chunk_ptr<T>(y, n, h, w, cc), f);
@@ -414,7 +453,6 @@ __global__ void row_reduce_kernel(ActView g, ActView y, const float* __restrict_
   const int cpp = y.c_len / CH;
   const int ppi = (y.H + rpp - 1) / rpp;          // partials per image
   const int nparts = y.B * ppi;
-  const int total = y.W * cpp;
   const bool inv = (blockDim.x % cpp) == 0;
   for (int r = blockIdx.x; r < nparts; r += gridDim.x) {
     const int n = r / ppi, h0 = (r - n * ppi) * rpp;
@@ -424,18 +462,29 @@ __global__ void row_reduce_kernel(ActView g, ActView y, const float* __restrict_
       const int cc = threadIdx.x % cpp;
 #pragma unroll
       for (int j = 0; j < CH; ++j) { a0[j] = 0.f; a1[j] = 0.f; sc[j] = scale[cc * CH + j]; sh[j] = shift[cc * CH + j]; }
+      const int wstep = blockDim.x / cpp;
       for (int h = h0; h < h1; ++h) {
-        for (int e = threadIdx.x; e < total; e += blockDim.x) {
-          const int w = e / cpp;
-          float f[CH], gg[CH];
-          Chunk<T>::unpack(*chunk_ptr<T>(y, n, h, w, cc), f);
-          if constexpr (WITH_G) Chunk<T>::unpack(*chunk_ptr<T>(g, n, h, w, cc), gg);
+        for (int w0 = threadIdx.x / cpp; w0 < y.W; w0 += PW_UNROLL * wstep) {
+          uint4 vy[PW_UNROLL], vg[PW_UNROLL];
 #pragma unroll
-          for (int j = 0; j < CH; ++j) {
-            const bool on = !relu || fmaf(f[j], sc[j], sh[j]) > 0.f;
-            const float m = WITH_G ? (on ? gg[j] : 0.f) : (on ? 1.f : 0.f);
-            a0[j] += m; a1[j] = fmaf(m, f[j], a1[j]);
-          }
+          for (int u = 0; u < PW_UNROLL; ++u)
+            if (w0 + u * wstep < y.W) {
+              vy[u] = *chunk_ptr<T>(y, n, h, w0 + u * wstep, cc);
+              if constexpr (WITH_G) vg[u] = *chunk_ptr<T>(g, n, h, w0 + u * wstep, cc);
+            }
+#pragma unroll
+          for (int u = 0; u < PW_UNROLL; ++u)
+            if (w0 + u * wstep < y.W) {
+              float f[CH], gg[CH];
+              Chunk<T>::unpack(vy[u], f);
+              if constexpr (WITH_G) Chunk<T>::unpack(vg[u], gg);
+#pragma unroll
+              for (int j = 0; j < CH; ++j) {
+                const bool on = !relu || fmaf(f[j], sc[j], sh[j]) > 0.f;
+                const float m = WITH_G ? (on ? gg[j] : 0.f) : (on ? 1.f : 0.f);
+                a0[j] += m; a1[j] = fmaf(m, f[j], a1[j]);
+              }
+            }
         }
       }
 #pragma unroll
@@ -509,6 +558,8 @@ extern "C" int insar_bnrelu_bwd_reduce(const InsarAct* dout, const InsarAct* y, 
 
 // Sum `rows` rows of a [rows][cols] fp32 slab into out[cols] (LDS), all threads of the block cooperating:
 // columns across lanes (coalesced), row lanes when cols < blockDim. `scratch` needs blockDim floats.
+#define COEF_THREADS 1024   // per-image coefficient kernels (se_excite, bnse_bwd_stage1): 16 waves
+
 __device__ __forceinline__ float strided_sum4(const float* __restrict__ p, int first, int rows, int step, int64_t ld) {
   // four independent partial sums so that the loads of one thread overlap (fixed order => deterministic)
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -527,7 +578,7 @@ __device__ __forceinline__ void block_colsum(const float* __restrict__ slab, int
     for (int c = threadIdx.x; c < cols; c += nt) out[c] = strided_sum4(slab + c, 0, rows, 1, cols);
     __syncthreads();
   } else {
-    const int lanes = nt / cols;                       // row lanes (cols is a power of two <= nt)
+    const int lanes = nt / cols;                       // row lanes; threads beyond lanes*cols idle
     const int c = threadIdx.x % cols, rl = threadIdx.x / cols;
     scratch[threadIdx.x] = rl < lanes ? strided_sum4(slab + c, rl, rows, lanes, cols) : 0.f;
     __syncthreads();
@@ -544,7 +595,7 @@ __device__ __forceinline__ void block_colsum(const float* __restrict__ slab, int
 // SE excitation (Unet-ChannalAttention.py:54-59,65-68): one block per image.
 // pooled[n][0][c] = sum mask, pooled[n][1][c] = sum mask*y  =>  mean_hw(z) = (scale*q1 + shift*q0)/HW
 // ---------------------------------------------------------------------------------------------
-__global__ void se_excite_kernel(InsarSeFwd d) {
+__global__ void __launch_bounds__(COEF_THREADS) se_excite_kernel(InsarSeFwd d) {
   extern __shared__ float sm[];
   float* sq = sm;            // [C]
   float* hid = sm + d.C;     // [Cr]
@@ -576,10 +627,12 @@ __global__ void se_excite_kernel(InsarSeFwd d) {
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
+  // gate[c] = sigmoid(sum_j w2[c][j] * hid[j]): one wave per row of w2, lanes over j (coalesced)
+  for (int c = wave; c < d.C; c += nw) {
     float acc = 0.f;
-    for (int j = 0; j < d.Cr; ++j) acc = fmaf(d.w2[(int64_t)c * d.Cr + j], hid[j], acc);
-    d.gate[(int64_t)n * d.C + c] = 1.f / (1.f + __expf(-acc));
+    for (int j = lane; j < d.Cr; j += 64) acc = fmaf(d.w2[(int64_t)c * d.Cr + j], hid[j], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) d.gate[(int64_t)n * d.C + c] = 1.f / (1.f + __expf(-acc));
   }
 }
 
@@ -587,9 +640,8 @@ extern "C" int insar_se_excite(const InsarSeFwd* d, void* stream) {
   if (!d || !d->part || !d->pooled || !d->scale || !d->shift || !d->w1 || !d->w2 || !d->sq || !d->hid || !d->gate)
     INSAR_FAIL(INSAR_E_ARG, "insar_se_excite: null pointer");
   if (d->B < 1 || d->C < 1 || d->Cr < 1 || d->C > 4096 || d->rows < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_se_excite: bad shape");
-  if (2 * d->C < 256 && (256 % (2 * d->C))) INSAR_FAIL(INSAR_E_SHAPE, "insar_se_excite: C must be a power of two below 128");
-  size_t lds = (size_t)(3 * d->C + d->Cr + 256) * sizeof(float);
-  hipLaunchKernelGGL(se_excite_kernel, dim3(d->B), dim3(256), lds, (hipStream_t)stream, *d);
+  size_t lds = (size_t)(3 * d->C + d->Cr + COEF_THREADS) * sizeof(float);
+  hipLaunchKernelGGL(se_excite_kernel, dim3(d->B), dim3(COEF_THREADS), lds, (hipStream_t)stream, *d);
   INSAR_CHECK_LAUNCH("insar_se_excite");
   return INSAR_OK;
 }
@@ -608,7 +660,7 @@ struct BnSeBwdArgs {
   float* ws; float* dconv_bias; int training;
 };
 
-__global__ void bnse_bwd_stage1(BnSeBwdArgs a) {
+__global__ void __launch_bounds__(COEF_THREADS) bnse_bwd_stage1(BnSeBwdArgs a) {
   extern __shared__ float sm[];
   const InsarBnSeBwd& d = a.d;
   float* du_s = sm;              // [C]
@@ -632,17 +684,24 @@ __global__ void bnse_bwd_stage1(BnSeBwdArgs a) {
       du_s[c] = du; du_g[c] = du;
     }
     __syncthreads();
+    // dt[j] = relu'(hid[j]) * sum_c du[c] * w2[c][j]: waves stride over the rows c of w2, lanes over j
+    // (coalesced), per-wave partials folded through LDS in wave order.
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-    for (int j = wave; j < d.Cr; j += nw) {
+    for (int j0 = 0; j0 < d.Cr; j0 += 64) {
+      const int j = j0 + lane;
       float acc = 0.f;
-      for (int c = lane; c < d.C; c += 64) acc = fmaf(du_s[c], d.w2[(int64_t)c * d.Cr + j], acc);
-      acc = wave_sum(acc);
-      if (lane == 0) {
-        const float dtv = d.hid[(int64_t)n * d.Cr + j] > 0.f ? acc : 0.f;
+      if (j < d.Cr)
+        for (int c = wave; c < d.C; c += nw) acc = fmaf(du_s[c], d.w2[(int64_t)c * d.Cr + j], acc);
+      scratch[wave * 64 + lane] = acc;
+      __syncthreads();
+      if (wave == 0 && j < d.Cr) {
+        float t = 0.f;
+        for (int w = 0; w < nw; ++w) t += scratch[w * 64 + lane];
+        const float dtv = d.hid[(int64_t)n * d.Cr + j] > 0.f ? t : 0.f;
         dt_s[j] = dtv; dt_g[j] = dtv;
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
   for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
     const float p2 = red_s[c];
@@ -709,11 +768,10 @@ extern "C" int insar_bnse_bwd_coef(const InsarBnSeBwd* d, const float* red, int3
     INSAR_FAIL(INSAR_E_ARG, "insar_bnse_bwd_coef: SE pointers missing");
   if (d->C > 8192 || d->B < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_bnse_bwd_coef: bad shape");
   if (rows < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_bnse_bwd_coef: rows");
-  if (2 * d->C < 256 && (256 % (2 * d->C))) INSAR_FAIL(INSAR_E_SHAPE, "insar_bnse_bwd_coef: C must be a power of two below 128");
   BnSeBwdArgs a; a.d = *d; a.red = red; a.rows = rows; a.scale = scale; a.shift = shift; a.ws = ws; a.dconv_bias = dconv_bias; a.training = training;
   hipStream_t s = (hipStream_t)stream;
-  size_t lds = (size_t)(3 * d->C + d->Cr + 1 + 256) * sizeof(float);
-  hipLaunchKernelGGL(bnse_bwd_stage1, dim3(d->B), dim3(256), lds, s, a);
+  size_t lds = (size_t)(3 * d->C + d->Cr + 1 + COEF_THREADS) * sizeof(float);
+  hipLaunchKernelGGL(bnse_bwd_stage1, dim3(d->B), dim3(COEF_THREADS), lds, s, a);
   int64_t work = d->C;
   if (d->use_se && (int64_t)d->C * d->Cr > work) work = (int64_t)d->C * d->Cr;
   hipLaunchKernelGGL(bnse_bwd_stage2, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a);
@@ -734,20 +792,62 @@ __global__ void bnrelu_bwd_apply_kernel(ActView g, ActView y, const float* __res
   const int total = y.W * cpp;
   const bool inv = (blockDim.x % cpp) == 0;
   float sc[CH], sh[CH], mu[CH], is[CH], ga[CH], cb[CH], c1[CH], c2[CH];
-  int cc_loaded = -1, n_loaded = -1;
+  if (inv) {
+    const int cc = threadIdx.x % cpp, wstep = blockDim.x / cpp;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int c = cc * CH + j;
+      sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c]; c1[j] = k1[c]; c2[j] = k2[c];
+      ga[j] = 1.f; cb[j] = 0.f;
+    }
+    int n_loaded = -1;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+      const int n = r / y.H, h = r - n * y.H;
+      if (n != n_loaded) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          if (gate) ga[j] = gate[(int64_t)n * y.c_len + cc * CH + j];
+          if (coefB) cb[j] = coefB[(int64_t)n * y.c_len + cc * CH + j];
+        }
+        n_loaded = n;
+      }
+      for (int w0 = threadIdx.x / cpp; w0 < y.W; w0 += PW_UNROLL * wstep) {
+        uint4 vy[PW_UNROLL], vg[PW_UNROLL];
+#pragma unroll
+        for (int u = 0; u < PW_UNROLL; ++u)
+          if (w0 + u * wstep < y.W) {
+            vy[u] = *chunk_ptr<T>(y, n, h, w0 + u * wstep, cc);
+            vg[u] = *chunk_ptr<T>(g, n, h, w0 + u * wstep, cc);
+          }
+#pragma unroll
+        for (int u = 0; u < PW_UNROLL; ++u)
+          if (w0 + u * wstep < y.W) {
+            float f[CH], gg[CH], o[CH];
+            Chunk<T>::unpack(vy[u], f);
+            Chunk<T>::unpack(vg[u], gg);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+              const bool on = !relu || fmaf(f[j], sc[j], sh[j]) > 0.f;
+              const float ge = on ? fmaf(gg[j], ga[j], cb[j]) : 0.f;
+              const float xh = (f[j] - mu[j]) * is[j];
+              o[j] = sc[j] * (ge - c1[j] - xh * c2[j]);
+            }
+            *chunk_ptr_w<T>(dy, n, h, w0 + u * wstep, cc) = Chunk<T>::pack(o);
+          }
+      }
+    }
+    return;
+  }
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const int n = r / y.H, h = r - n * y.H;
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
       const int w = e / cpp, cc = e - w * cpp;
-      if (!inv || cc != cc_loaded || n != n_loaded) {
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-          const int c = cc * CH + j;
-          sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c]; c1[j] = k1[c]; c2[j] = k2[c];
-          ga[j] = gate ? gate[(int64_t)n * y.c_len + c] : 1.f;
-          cb[j] = coefB ? coefB[(int64_t)n * y.c_len + c] : 0.f;
-        }
-        cc_loaded = cc; n_loaded = n;
+      for (int j = 0; j < CH; ++j) {
+        const int c = cc * CH + j;
+        sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c]; c1[j] = k1[c]; c2[j] = k2[c];
+        ga[j] = gate ? gate[(int64_t)n * y.c_len + c] : 1.f;
+        cb[j] = coefB ? coefB[(int64_t)n * y.c_len + c] : 0.f;
       }
       float f[CH], gg[CH], o[CH];
       Chunk<T>::unpack(*chunk_ptr<T>(y, n, h, w, cc), f);

@@ -8,7 +8,9 @@ PyTorch only provides device memory, streams and the autograd edge at the module
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -57,7 +59,13 @@ class Ctx:
         self.code = _lib.dtype_code(dtype)
         self.esize = 2 if dtype == torch.bfloat16 else 4
         self.ch = 16 // self.esize
-        self._colsum_tmp = torch.empty(1 << 20, dtype=torch.float32, device=device)
+        self._colsum_tmp: Dict[int, torch.Tensor] = {}
+        # Weight gradients (wgrad GEMM + slab folds) depend on nothing but a layer's input and its dy, and
+        # nothing in backward depends on them: they go to a second HIP stream so that they overlap the
+        # HBM-bound BN/ReLU backward passes and the next dgrad on the main stream. INSAR_SIDE_STREAM=0 disables.
+        self.side = (torch.cuda.Stream(device=device)
+                     if device.type == "cuda" and os.environ.get("INSAR_SIDE_STREAM", "1") != "0" else None)
+        self._side_busy = False
         self._wgrad_part: Optional[torch.Tensor] = None
         self._wgrad_fold: Optional[torch.Tensor] = None
         self._tables: Dict[tuple, torch.Tensor] = {}
@@ -73,15 +81,33 @@ class Ctx:
             self._consts[key] = torch.full((n,), value, dtype=torch.float32, device=self.device)
         return self._consts[key]
 
+    @contextlib.contextmanager
+    def side_stream(self):
+        """Run the enclosed launches on the side stream, ordered after everything enqueued so far on the
+        current stream. Per-kernel timing passes (PROFILER) stay on one stream."""
+        if self.side is None or PROFILER is not None:
+            yield
+            return
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            yield
+        self._side_busy = True
+
+    def join_side(self) -> None:
+        """Order the current stream after the side stream's work (end of backward, before a gradient bucket
+        is handed to the all-reduce)."""
+        if self._side_busy:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self._side_busy = False
+
     def colsum(self, part: torch.Tensor, out: torch.Tensor, segments: int, rows: int, cols: int,
                accumulate: bool = False) -> None:
-        need = 0
-        if rows > 256:
-            need = ((rows + 127) // 128) * segments * cols
-            if need > self._colsum_tmp.numel():
-                self._colsum_tmp = torch.empty(need, dtype=torch.float32, device=self.device)
-        call("insar_colsum", ptr(part), ptr(out), segments, rows, cols, int(accumulate),
-             ptr(self._colsum_tmp), self._colsum_tmp.numel(), _lib.stream_ptr())
+        s = _lib.stream_ptr()
+        tmp = self._colsum_tmp.get(s)
+        need = ((rows + 127) // 128) * segments * cols if rows > 256 else 0
+        if tmp is None or need > tmp.numel():
+            tmp = self._colsum_tmp[s] = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=self.device)
+        call("insar_colsum", ptr(part), ptr(out), segments, rows, cols, int(accumulate), ptr(tmp), tmp.numel(), s)
 
     def wgrad_part(self, floats: int) -> torch.Tensor:
         if self._wgrad_part is None or self._wgrad_part.numel() < floats:
@@ -402,16 +428,17 @@ class ConvBN:
         call("insar_bnrelu_bwd_apply", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.mean),
              ptr(self.invstd), ptr(se.gate) if se else 0, ptr(se.coefB) if se else 0, ptr(self.k1), ptr(self.k2),
              self.dy.ref, 1, s)
-        # weight gradient
+        # weight gradient (side stream: reads x and dy, writes only the gradient sink)
         gw = sink.view(self.conv.weight)
-        if self.small:
-            nb = call("insar_conv3x3_small_wgrad_blocks", B, H)
-            cols = self.cout * self.cin * 9
-            part = ctx.wgrad_part(nb * cols)
-            call("insar_conv3x3_small_wgrad", self.x.ref, self.dy.ref, ptr(part), s)
-            ctx.colsum(part, gw, 1, nb, cols)
-        else:
-            _wgrad_conv3(ctx, self.x, self.dy, gw)
+        with ctx.side_stream():
+            if self.small:
+                nb = call("insar_conv3x3_small_wgrad_blocks", B, H)
+                cols = self.cout * self.cin * 9
+                part = ctx.wgrad_part(nb * cols)
+                call("insar_conv3x3_small_wgrad", self.x.ref, self.dy.ref, ptr(part), _lib.stream_ptr())
+                ctx.colsum(part, gw, 1, nb, cols)
+            else:
+                _wgrad_conv3(ctx, self.x, self.dy, gw)
         if dx is not None:
             if self.small:
                 raise _lib.InsarError(f"{self.name}: input gradient of the direct first-layer conv is not provided")
@@ -543,16 +570,17 @@ class UpPlan:
         tn = 128 if (ctx.code == _lib.BF16 and self.cout % 128 == 0) else 64
         tiles = 4 * (self.cin // tm) * (self.cout // tn)
         nsplit = _wgrad_nsplit(tiles, mpad // WG_BKP, 4 * self.cout * self.cin, tm, tn, ctx.esize)
-        part = ctx.wgrad_part(nsplit * 4 * self.cout * self.cin)
-        d = InsarWgrad()
-        d.x, d.dy = x.desc, dout.desc
-        d.tabx, d.tabdy, d.part = ptr(tabx), ptr(tabdy), ptr(part)
-        d.Mpad, d.nsplit, d.ntaps = mpad, nsplit, 4
-        for i, (a, b) in enumerate(_TAPS2):
-            d.offx[i] = 0
-            d.offdy[i] = a * (dout.W + 2) + b
-        _launch_wgrad(d, B * h * w, self.cin, self.cout, 4, ctx.code)
-        ctx.wgrad_finish(part, sink.view(self.mod.weight), nsplit, 4, self.cout, self.cin, 1)
+        with ctx.side_stream():
+            part = ctx.wgrad_part(nsplit * 4 * self.cout * self.cin)
+            d = InsarWgrad()
+            d.x, d.dy = x.desc, dout.desc
+            d.tabx, d.tabdy, d.part = ptr(tabx), ptr(tabdy), ptr(part)
+            d.Mpad, d.nsplit, d.ntaps = mpad, nsplit, 4
+            for i, (a, b) in enumerate(_TAPS2):
+                d.offx[i] = 0
+                d.offdy[i] = a * (dout.W + 2) + b
+            _launch_wgrad(d, B * h * w, self.cin, self.cout, 4, ctx.code)
+            ctx.wgrad_finish(part, sink.view(self.mod.weight), nsplit, 4, self.cout, self.cin, 1)
         if dx is not None:
             _igemm(dout, dx, self.w.dgrad(), self.cin, h, w, 2, _TAPS2, 0)
 
@@ -718,4 +746,5 @@ class UNetPlan:
                      self.dcat[l - 1].slice(0, w[l - 1]).ref, 1, s())
             if on_bucket is not None:
                 on_bucket(self, ("enc", l))
+        self.ctx.join_side()
         return [sink.view(p) for p in self.grad_params]

@@ -205,6 +205,7 @@ class _DoubleConvRunner:
         if need_dx and self.dx is None:
             raise _lib.InsarError("DoubleConv: input gradient is not provided for in_channels <= 4 (first layer)")
         self.plan.backward(self.dout, self.sink, self.training, self.dx if need_dx else None)
+        self.ctx.join_side()
         dx = unpack_output(self.dx) if need_dx else None
         return dx, [self.sink.view(p) for p in self.params]
 

@@ -89,6 +89,7 @@ class DataParallel(torch.nn.Module):
         ends, closes = plan.stage_ends, plan.bucket_closes(self.min_elems)
         if self._stage in closes:
             end = ends[self._stage]
+            plan.ctx.join_side()        # the bucket's weight gradients were computed on the side stream
             self.reducer.reduce_slice(plan.sink.flat(), self._begin, end)
             self._begin = end
         self._stage += 1
@@ -96,6 +97,7 @@ class DataParallel(torch.nn.Module):
     def _on_done(self, plan) -> None:
         total = plan.sink.flat().numel()
         if self._begin < total:
+            plan.ctx.join_side()
             self.reducer.reduce_slice(plan.sink.flat(), self._begin, total)
         self.reducer.finish()
         self._stage = 0
