@@ -130,6 +130,7 @@ def main() -> int:
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(i)
+    host_enqueue = time.perf_counter() - t0      # host time to enqueue the K steps (no sync inside a step)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -174,6 +175,7 @@ def main() -> int:
                                    f"per GPU, {'Dice+CE' if args.loss == 'dice_ce' else 'CE'} + Adam(lr=1e-4) training on synthetic InSAR tiles",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "final_loss": round(final_loss, 5),
+            "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 3),
             "frac_of_mfma_roofline": round(per_gpu * FLOP_PER_TILE_256 * (args.size / 256) ** 2 / (PEAK_BF16_TFLOPS * 1e12), 4),
             "frac_of_hbm_roofline": round(per_gpu * BYTES_PER_TILE_BF16_B16 * (args.size / 256) ** 2 / (PEAK_HBM_GBS * 1e9), 4),
         }

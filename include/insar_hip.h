@@ -253,6 +253,12 @@ int insar_dice(const float* logits, const int64_t* target, int32_t B, int32_t K,
                int64_t ignore_index, float smooth, float* dlogits, float* loss_out, float* ws,
                void* stream);
 
+/* ce_weight*CE + dice_weight*Dice in one statistics pass + one gradient pass. ws: float[3 + 3K + blocks*(2 + 3K)];
+ * loss_out[0] = combined, [1] = CE, [2] = Dice; dlogits = gradient of the combined loss. */
+int insar_dice_ce(const float* logits, const int64_t* target, int32_t B, int32_t K, int64_t HW,
+                  int64_t ignore_index, float smooth, float ce_weight, float dice_weight, float* dlogits,
+                  float* loss_out, float* ws, void* stream);
+
 /* ---- metrics (compute_metrics, :215-269): argmax (ties -> lower class) + TP/FP/FN counts -------- */
 int insar_confusion(const float* logits, const int64_t* target, int32_t B, int32_t K, int64_t HW,
                     int64_t ignore_index, int64_t* counts /*[3][K], zeroed by the call*/, void* stream);

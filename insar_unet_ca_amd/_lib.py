@@ -103,6 +103,7 @@ _SIGNATURES = {
     "insar_ce_blocks": [_L],
     "insar_cross_entropy": [_P, _P, _I, _I, _L, _L, _P, _P, _P, _P],
     "insar_dice": [_P, _P, _I, _I, _L, _L, _F, _P, _P, _P, _P],
+    "insar_dice_ce": [_P, _P, _I, _I, _L, _L, _F, _F, _F, _P, _P, _P, _P],
     "insar_confusion": [_P, _P, _I, _I, _L, _L, _P, _P],
     "insar_adam_step": [_P, _P, _I, _I, _F, _F, _F, _F, _F, _F, _F, _P],
     "insar_scale_f32": [_P, _L, _F, _P],

@@ -203,6 +203,133 @@ extern "C" int insar_dice(const float* logits, const int64_t* target, int32_t B,
 }
 
 // ---------------------------------------------------------------------------------------------
+// ce_weight * CrossEntropy + dice_weight * Dice in three launches (one statistics pass over the logits,
+// one fold, one gradient pass) instead of the seven of the two separate entry points.
+// ws layout (floats): [0] n_valid [1] 1/n_valid [2] sum CE  [3 .. 3+3K) totals I,P,T ;
+//                     then per block: [count, ce_sum, I[K], P[K], T[K]]  (2 + 3K floats each)
+// ---------------------------------------------------------------------------------------------
+__global__ void dicece_partial_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, int K, int64_t HW,
+                                      int64_t npix, int64_t ignore_index, float* ws) {
+  __shared__ float red[8];
+  float aI[LO_MAXK], aP[LO_MAXK], aT[LO_MAXK];
+  float cnt = 0.f, lsum = 0.f;
+#pragma unroll
+  for (int k = 0; k < LO_MAXK; ++k) { aI[k] = 0.f; aP[k] = 0.f; aT[k] = 0.f; }
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = target[p];
+    if (t == ignore_index) continue;
+    const int64_t n = p / HW, hw = p - n * HW;
+    const float* lp = logits + n * K * HW + hw;
+    float mx = lp[0];
+    for (int k = 1; k < K; ++k) mx = fmaxf(mx, lp[k * HW]);
+    float se = 0.f;
+    for (int k = 0; k < K; ++k) se += __expf(lp[k * HW] - mx);
+    const float rse = 1.f / se;
+    const float lse = mx + __logf(se);
+    cnt += 1.f;
+#pragma unroll
+    for (int k = 0; k < LO_MAXK; ++k) {
+      if (k < K) {
+        const float v = lp[k * HW];
+        const float pr = __expf(v - mx) * rse;
+        aP[k] += pr;
+        if (k == t) { aI[k] += pr; aT[k] += 1.f; lsum += lse - v; }
+      }
+    }
+  }
+  float* out = ws + 3 + 3 * K + (int64_t)blockIdx.x * (2 + 3 * K);
+  const float c = block_sum(cnt, red), l = block_sum(lsum, red);
+  if (threadIdx.x == 0) { out[0] = c; out[1] = l; }
+#pragma unroll
+  for (int k = 0; k < LO_MAXK; ++k) {
+    if (k < K) {
+      const float i = block_sum(aI[k], red), pp = block_sum(aP[k], red), tt = block_sum(aT[k], red);
+      if (threadIdx.x == 0) { out[2 + k] = i; out[2 + K + k] = pp; out[2 + 2 * K + k] = tt; }
+    }
+  }
+}
+
+__global__ void dicece_final_kernel(float* ws, int K, int nb, float smooth, float ce_w, float dice_w, float* loss_out) {
+  __shared__ float red[8];
+  __shared__ float tot[2 + 3 * LO_MAXK];
+  const int stride = 2 + 3 * K;
+  for (int q = 0; q < stride; ++q) {
+    float c = 0.f;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) c += ws[3 + 3 * K + (int64_t)i * stride + q];
+    c = block_sum(c, red);
+    if (threadIdx.x == 0) tot[q] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float nvalid = tot[0];
+    ws[0] = nvalid; ws[1] = 1.f / nvalid; ws[2] = tot[1];
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+      ws[3 + k] = tot[2 + k]; ws[3 + K + k] = tot[2 + K + k]; ws[3 + 2 * K + k] = tot[2 + 2 * K + k];
+      acc += (2.f * tot[2 + k] + smooth) / (tot[2 + K + k] + tot[2 + 2 * K + k] + smooth);
+    }
+    const float ce = tot[1] / nvalid, dice = 1.f - acc / (float)K;
+    loss_out[0] = ce_w * ce + dice_w * dice;
+    loss_out[1] = ce;
+    loss_out[2] = dice;
+  }
+}
+
+__global__ void dicece_grad_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, int K, int64_t HW,
+                                   int64_t npix, int64_t ignore_index, float smooth, float ce_w, float dice_w,
+                                   const float* __restrict__ ws, float* __restrict__ dlogits) {
+  float num[LO_MAXK], den[LO_MAXK];
+  const float inv = ws[1] * ce_w;
+#pragma unroll
+  for (int k = 0; k < LO_MAXK; ++k) {
+    num[k] = k < K ? 2.f * ws[3 + k] + smooth : 0.f;
+    den[k] = k < K ? ws[3 + K + k] + ws[3 + 2 * K + k] + smooth : 1.f;
+  }
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = p / HW, hw = p - n * HW;
+    const float* lp = logits + n * K * HW + hw;
+    float* gp = dlogits + n * K * HW + hw;
+    const int64_t t = target[p];
+    if (t == ignore_index) { for (int k = 0; k < K; ++k) gp[k * HW] = 0.f; continue; }
+    float mx = lp[0];
+    for (int k = 1; k < K; ++k) mx = fmaxf(mx, lp[k * HW]);
+    float se = 0.f;
+    for (int k = 0; k < K; ++k) se += __expf(lp[k * HW] - mx);
+    const float rse = 1.f / se;
+    float pr[LO_MAXK], gk[LO_MAXK];
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < LO_MAXK; ++k) {
+      if (k < K) {
+        pr[k] = __expf(lp[k * HW] - mx) * rse;
+        gk[k] = -((k == t ? 2.f * den[k] : 0.f) - num[k]) / (den[k] * den[k]) / (float)K;
+        dot = fmaf(pr[k], gk[k], dot);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < LO_MAXK; ++k)
+      if (k < K) gp[k * HW] = (pr[k] - (k == t ? 1.f : 0.f)) * inv + dice_w * pr[k] * (gk[k] - dot);
+  }
+}
+
+extern "C" int insar_dice_ce(const float* logits, const int64_t* target, int32_t B, int32_t K, int64_t HW, int64_t ignore_index,
+                             float smooth, float ce_weight, float dice_weight, float* dlogits, float* loss_out, float* ws,
+                             void* stream) {
+  if (!logits || !target || !dlogits || !loss_out || !ws) INSAR_FAIL(INSAR_E_ARG, "insar_dice_ce: null pointer");
+  if (K < 1 || K > LO_MAXK) INSAR_FAIL(INSAR_E_SHAPE, "insar_dice_ce: num_classes=%d must be 1..%d", K, LO_MAXK);
+  if (B < 1 || HW < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_dice_ce: bad shape");
+  const int64_t npix = (int64_t)B * HW;
+  const int nb = insar_ce_blocks(npix);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(dicece_partial_kernel, dim3(nb), dim3(LO_THREADS), 0, s, logits, target, K, HW, npix, ignore_index, ws);
+  hipLaunchKernelGGL(dicece_final_kernel, dim3(1), dim3(LO_THREADS), 0, s, ws, K, nb, smooth, ce_weight, dice_weight, loss_out);
+  hipLaunchKernelGGL(dicece_grad_kernel, dim3(nb), dim3(LO_THREADS), 0, s, logits, target, K, HW, npix, ignore_index, smooth,
+                     ce_weight, dice_weight, ws, dlogits);
+  INSAR_CHECK_LAUNCH("insar_dice_ce");
+  return INSAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // compute_metrics counts (Unet-ChannalAttention.py:220-240): argmax over classes with ties going to
 // the LOWER class index (torch.max, :220), pixels with target == 255 ignored (:223);
 // counts[0][c] = TP, counts[1][c] = FP, counts[2][c] = FN  (int64, exact).

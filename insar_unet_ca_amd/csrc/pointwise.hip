@@ -618,6 +618,7 @@ __global__ void __launch_bounds__(COEF_THREADS) se_excite_kernel(InsarSeFwd d) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   for (int j = wave; j < d.Cr; j += nw) {
     float acc = 0.f;
+#pragma unroll 8
     for (int c = lane; c < d.C; c += 64) acc = fmaf(d.w1[(int64_t)j * d.C + c], sq[c], acc);
     acc = wave_sum(acc);
     if (lane == 0) {
@@ -628,11 +629,22 @@ __global__ void __launch_bounds__(COEF_THREADS) se_excite_kernel(InsarSeFwd d) {
   }
   __syncthreads();
   // gate[c] = sigmoid(sum_j w2[c][j] * hid[j]): one wave per row of w2, lanes over j (coalesced)
-  for (int c = wave; c < d.C; c += nw) {
-    float acc = 0.f;
-    for (int j = lane; j < d.Cr; j += 64) acc = fmaf(d.w2[(int64_t)c * d.Cr + j], hid[j], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) d.gate[(int64_t)n * d.C + c] = 1.f / (1.f + __expf(-acc));
+  // (8 rows per trip so that their loads are in flight together: this block is latency-bound)
+  for (int c0 = wave; c0 < d.C; c0 += 8 * nw) {
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + u * nw;
+      acc[u] = 0.f;
+      if (c < d.C)
+        for (int j = lane; j < d.Cr; j += 64) acc[u] = fmaf(d.w2[(int64_t)c * d.Cr + j], hid[j], acc[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + u * nw;
+      const float t = wave_sum(acc[u]);
+      if (lane == 0 && c < d.C) d.gate[(int64_t)n * d.C + c] = 1.f / (1.f + __expf(-t));
+    }
   }
 }
 
@@ -690,8 +702,10 @@ __global__ void __launch_bounds__(COEF_THREADS) bnse_bwd_stage1(BnSeBwdArgs a) {
     for (int j0 = 0; j0 < d.Cr; j0 += 64) {
       const int j = j0 + lane;
       float acc = 0.f;
-      if (j < d.Cr)
+      if (j < d.Cr) {
+#pragma unroll 8
         for (int c = wave; c < d.C; c += nw) acc = fmaf(du_s[c], d.w2[(int64_t)c * d.Cr + j], acc);
+      }
       scratch[wave * 64 + lane] = acc;
       __syncthreads();
       if (wave == 0 && j < d.Cr) {
@@ -711,6 +725,7 @@ __global__ void __launch_bounds__(COEF_THREADS) bnse_bwd_stage1(BnSeBwdArgs a) {
     float s = 1.f, cb = 0.f, cnt = 0.f, p5 = 0.f;
     if (d.use_se) {
       float dsq = 0.f;
+#pragma unroll 8
       for (int j = 0; j < d.Cr; ++j) dsq = fmaf(dt_s[j], d.w1[(int64_t)j * d.C + c], dsq);
       cb = dsq * inv_hw;
       s = d.gate[(int64_t)n * d.C + c];

@@ -545,6 +545,7 @@ class UpPlan:
         self.bias_rpp = _rows_per_part(out.B, out.H)
         self.bias_rows = out.B * -(-out.H // self.bias_rpp)
         self.bias_part = ctx.f32(self.bias_rows, 2, self.cout)
+        self.bias_sum = ctx.f32(2, self.cout)
 
     def params(self):
         return [self.mod.weight, self.mod.bias]
@@ -557,12 +558,6 @@ class UpPlan:
         """dout: gradient slice wrt this layer's output (upper half of the dcat buffer)."""
         ctx, s = self.ctx, _lib.stream_ptr()
         x, B, h, w = self.x, self.x.B, self.x.H, self.x.W
-        if self.mod.bias is not None:     # dbias = sum over pixels of dout (mask-free row reduction)
-            call("insar_bnrelu_bwd_reduce", dout.ref, dout.ref, ptr(ctx.const(0.0, self.cout)),
-                 ptr(ctx.const(1.0, self.cout)), ptr(self.bias_part), 0, self.bias_rpp, s)
-            tmp = ctx.f32(2, self.cout)
-            ctx.colsum(self.bias_part, tmp, 1, self.bias_rows, 2 * self.cout)
-            sink.view(self.mod.bias).copy_(tmp[0])
         tabx = ctx.pixel_table(B, h, w, 1, h, w, 0)
         tabdy = ctx.pixel_table(B, h, w, 2, dout.H, dout.W, 0)
         mpad = tabx.numel()
@@ -571,6 +566,11 @@ class UpPlan:
         tiles = 4 * (self.cin // tm) * (self.cout // tn)
         nsplit = _wgrad_nsplit(tiles, mpad // WG_BKP, 4 * self.cout * self.cin, tm, tn, ctx.esize)
         with ctx.side_stream():
+            if self.mod.bias is not None:     # dbias = sum over pixels of dout (mask-free row reduction)
+                call("insar_bnrelu_bwd_reduce", dout.ref, dout.ref, ptr(ctx.const(0.0, self.cout)),
+                     ptr(ctx.const(1.0, self.cout)), ptr(self.bias_part), 0, self.bias_rpp, _lib.stream_ptr())
+                ctx.colsum(self.bias_part, self.bias_sum, 1, self.bias_rows, 2 * self.cout)
+                sink.view(self.mod.bias).copy_(self.bias_sum[0])
             part = ctx.wgrad_part(nsplit * 4 * self.cout * self.cin)
             d = InsarWgrad()
             d.x, d.dy = x.desc, dout.desc
@@ -609,11 +609,12 @@ class OutConvPlan:
     def backward(self, dlogits: torch.Tensor, sink: GradSink, dx: Act) -> None:
         call("insar_conv1x1_out_bwd", self.x.ref, ptr(self.mod.weight.detach()), ptr(dlogits), self.K, dx.ref,
              ptr(self.part), _lib.stream_ptr())
-        self.ctx.colsum(self.part, self.folded, 1, self.nb, self.cols)
-        kc = self.K * self.cin
-        sink.view(self.mod.weight).view(-1).copy_(self.folded[:kc])
-        if self.mod.bias is not None:
-            sink.view(self.mod.bias).copy_(self.folded[kc:])
+        with self.ctx.side_stream():            # folds are off the critical path
+            self.ctx.colsum(self.part, self.folded, 1, self.nb, self.cols)
+            kc = self.K * self.cin
+            sink.view(self.mod.weight).view(-1).copy_(self.folded[:kc])
+            if self.mod.bias is not None:
+                sink.view(self.mod.bias).copy_(self.folded[kc:])
 
 
 def pack_input(x: torch.Tensor, dst: Act) -> None:

@@ -72,6 +72,28 @@ class _DiceFn(torch.autograd.Function):
         return (ctx.dl * g).to(ctx.in_dtype), None, None, None
 
 
+class _DiceCEFn(torch.autograd.Function):
+    """ce_weight*CE + dice_weight*Dice: one statistics pass and one gradient pass over the logits."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index, smooth, ce_weight, dice_weight):
+        lg, tg, B, K, HW = _prep(logits, target, "DiceCELoss")
+        dl = torch.empty_like(lg)
+        nb = call("insar_ce_blocks", B * HW)
+        ws = torch.empty(3 + 3 * K + nb * (2 + 3 * K), dtype=torch.float32, device=lg.device)
+        out = torch.empty(3, dtype=torch.float32, device=lg.device)
+        call("insar_dice_ce", ptr(lg), ptr(tg), B, K, HW, ignore_index, float(smooth), float(ce_weight), float(dice_weight),
+             ptr(dl), ptr(out), ptr(ws), _lib.stream_ptr())
+        ctx.dl = dl
+        ctx.in_dtype = logits.dtype
+        ctx.parts = out           # [combined, ce, dice] for logging
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.dl * g).to(ctx.in_dtype), None, None, None, None, None
+
+
 class CrossEntropyLoss(nn.Module):
     """Drop-in for nn.CrossEntropyLoss(ignore_index=...) with mean reduction."""
 
@@ -106,4 +128,4 @@ class DiceCELoss(nn.Module):
         self.ce_weight, self.dice_weight = ce_weight, dice_weight
 
     def forward(self, logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
-        return self.ce_weight * self.ce(logits, target) + self.dice_weight * self.dice(logits, target)
+        return _DiceCEFn.apply(logits, target, self.ce.ignore_index, self.dice.smooth, self.ce_weight, self.dice_weight)

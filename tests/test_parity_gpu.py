@@ -564,6 +564,25 @@ def test_dice_against_oracle_definition(dev):
     assert max_rel(a.grad, b.grad) <= 1e-4
 
 
+@pytest.mark.parametrize("wce,wd", [(1.0, 1.0), (0.3, 0.7)])
+def test_fused_dice_ce_against_oracle(dev, wce, wd):
+    """DiceCELoss (one statistics pass + one gradient pass) == ce_weight*CE + dice_weight*Dice of the oracle."""
+    import insar_unet_ca_amd as iu
+    lg = cf.make_input((3, 2, 32, 48), 0.9) * 3.0
+    tgt = cf.make_target((3, 32, 48), ignore_every=5)
+    a = lg.clone().to(dev).requires_grad_(True)
+    crit = iu.DiceCELoss(ignore_index=255, ce_weight=wce, dice_weight=wd)
+    d = crit(a, tgt.to(dev))
+    d.backward()
+    b = lg.clone().requires_grad_(True)
+    r = wce * orc.cross_entropy(b, tgt) + wd * orc.soft_dice_loss(b, tgt)
+    r.backward()
+    assert abs(float(d.detach()) - float(r.detach())) <= 2e-6
+    assert max_rel(a.grad, b.grad) <= 1e-4
+    sep = wce * iu.CrossEntropyLoss(ignore_index=255)(lg.to(dev), tgt.to(dev)) + wd * iu.DiceLoss(ignore_index=255)(lg.to(dev), tgt.to(dev))
+    assert abs(float(d.detach()) - float(sep)) <= 2e-6
+
+
 @pytest.mark.parametrize("case", ["three_of_four", "all_tie", "class1_absent", "ignore255"])
 def test_metrics_counts_kat(dev, golden, case):
     g6 = golden("g6_metrics")
