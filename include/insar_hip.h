@@ -70,6 +70,10 @@ int insar_weight_prep(const float* in, void* out, int32_t dtype, int32_t T, int3
  * {in*, out*, T, N, K, st, sn, sk, first_tile, dtype}; a job owns T*ceil(N/32)*ceil(K/32) consecutive tiles
  * starting at first_tile; total_tiles = sum over jobs. */
 int insar_weight_prep_batch(const int64_t* jobs, int32_t njobs, int64_t total_tiles, void* stream);
+/* Paired form: both GEMM layouts from one read of the fp32 master in[a][b][T] (T <= 9 taps contiguous):
+ * out_ab[t][a][b] and out_ba[t][b][a]. jobs: int64[njobs][8] = {in*, out_ab*, out_ba*, A, B, T, first_tile,
+ * dtype}; one work-group per 32x32 (a x b) tile, tiles numbered job after job. */
+int insar_weight_prep_pair_batch(const int64_t* jobs, int32_t njobs, int64_t total_tiles, void* stream);
 
 /* ---- implicit-GEMM convolution family (MFMA) ------------------------------------------------
  * y[pix(m), n] = sum_{tap, k} x[in_pix(m, tap), k] * w[tap][n][k]  (+ bias[n])
@@ -110,6 +114,15 @@ int insar_conv3x3_flat_ok(const InsarAct* x, int32_t N);
 int insar_conv3x3_flat_num_mtiles(const InsarAct* x);
 int insar_conv3x3_flat(const InsarAct* x, const InsarAct* y, const void* w, int32_t flip, float* stats,
                        void* stream);
+
+/* ---- 3x3 conv with 64 -> 64 channels, bf16 (the full-resolution level; :81,84 and their dgrad) -------
+ * Persistent work-groups, weights in registers, activations through a rolling LDS window over the flat
+ * padded pixel space (csrc/conv3x3_c64.hip). Same operands and tap order as insar_conv3x3_flat.
+ * stats: [insar_conv3x3_c64_rows(x)][2][64] BatchNorm partial sums (one row per work-group) or null. */
+int insar_conv3x3_c64_ok(const InsarAct* x, int32_t N);
+int insar_conv3x3_c64_rows(const InsarAct* x);
+int insar_conv3x3_c64(const InsarAct* x, const InsarAct* y, const void* w, int32_t flip, float* stats,
+                      void* stream);
 
 /* ---- weight-gradient GEMM (MFMA, split-K over pixels, no atomics) ------------------------------
  * part[split][tap][co][ci] = sum_{p in split} dy[pixB(p,tap), co] * x[pixA(p,tap), ci]

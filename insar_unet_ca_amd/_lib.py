@@ -73,12 +73,16 @@ _SIGNATURES = {
     "insar_unpack_nchw": [_AP, _P, _P],
     "insar_weight_prep": [_P, _P, _I, _I, _I, _I, _L, _L, _L, _P],
     "insar_weight_prep_batch": [_P, _I, _L, _P],
+    "insar_weight_prep_pair_batch": [_P, _I, _L, _P],
     "insar_igemm_num_mtiles": [_L, _I],
     "insar_igemm_tile_rows": [_L, _I],
     "insar_igemm": [C.POINTER(InsarIgemm), _P],
     "insar_conv3x3_flat_ok": [_AP, _I],
     "insar_conv3x3_flat_num_mtiles": [_AP],
     "insar_conv3x3_flat": [_AP, _AP, _P, _I, _P, _P],
+    "insar_conv3x3_c64_ok": [_AP, _I],
+    "insar_conv3x3_c64_rows": [_AP],
+    "insar_conv3x3_c64": [_AP, _AP, _P, _I, _P, _P],
     "insar_wgrad": [C.POINTER(InsarWgrad), _P],
     "insar_wgrad_reduce": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "insar_wgrad_fold": [_P, _P, _L, _I, _I, _P],
@@ -141,7 +145,7 @@ def load():
     return lib
 
 
-_COUNT_ONLY = {"insar_igemm_num_mtiles", "insar_igemm_tile_rows", "insar_conv3x3_flat_ok", "insar_conv3x3_flat_num_mtiles", "insar_conv3x3_small_wgrad_blocks", "insar_conv1x1_out_bwd_blocks",
+_COUNT_ONLY = {"insar_igemm_num_mtiles", "insar_igemm_tile_rows", "insar_conv3x3_flat_ok", "insar_conv3x3_flat_num_mtiles", "insar_conv3x3_c64_ok", "insar_conv3x3_c64_rows", "insar_conv3x3_small_wgrad_blocks", "insar_conv1x1_out_bwd_blocks",
                "insar_ce_blocks"}
 
 

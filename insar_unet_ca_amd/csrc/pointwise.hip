@@ -225,6 +225,65 @@ extern "C" int insar_weight_prep_batch(const int64_t* jobs, int32_t njobs, int64
   return INSAR_OK;
 }
 
+// Paired form: both GEMM layouts of a weight from ONE read of the master. in[a][b][T] fp32 (T taps
+// contiguous: Conv2d (Co,Ci,3,3) -> a=co, b=ci, T=9; ConvTranspose2d (Ci,Co,2,2) -> a=ci, b=co, T=4) goes to
+// out_ab[t][a][b] and out_ba[t][b][a] in the compute dtype. A block takes a 32(a) x 32(b) tile with all its
+// taps: 32 contiguous runs of 32*T floats in, 2*T*32 rows of 32 elements out.
+// jobs: int64[njobs][8] = {in*, out_ab*, out_ba*, A, B, T, first_tile, dtype}; T <= 9.
+template <typename TO>
+__device__ __forceinline__ void weight_prep_pair_tile(const float* __restrict__ in, TO* __restrict__ oab, TO* __restrict__ oba,
+                                                      int A, int B, int T, int a0, int b0, float (*tile)[32 * 9 + 1]) {
+  const int nb = min(32, B - b0), na = min(32, A - a0);
+  const int rowlen = nb * T;
+  const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;       // 8 groups of 32 lanes
+  for (int a = grp; a < na; a += 8) {
+    const float* src = in + ((int64_t)(a0 + a) * B + b0) * T;
+    for (int i = lane; i < rowlen; i += 32) tile[a][i] = src[i];
+  }
+  __syncthreads();
+  for (int r = grp; r < T * 32; r += 8) {
+    const int t = r >> 5, q = r & 31;
+    if (q < na && lane < nb) {                                      // row (t, a = q), lanes over b
+      const float v = tile[q][lane * T + t];
+      const int64_t o = ((int64_t)t * A + a0 + q) * B + b0 + lane;
+      if constexpr (sizeof(TO) == 2) ((uint16_t*)oab)[o] = f32_to_bf16(v); else ((float*)oab)[o] = v;
+    }
+    if (q < nb && lane < na) {                                      // row (t, b = q), lanes over a
+      const float v = tile[lane][q * T + t];
+      const int64_t o = ((int64_t)t * B + b0 + q) * A + a0 + lane;
+      if constexpr (sizeof(TO) == 2) ((uint16_t*)oba)[o] = f32_to_bf16(v); else ((float*)oba)[o] = v;
+    }
+  }
+}
+
+__global__ void weight_prep_pair_kernel(const int64_t* __restrict__ jobs, int njobs) {
+  __shared__ float tile[32][32 * 9 + 1];
+  __shared__ int sjob;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = njobs - 1;                       // last job whose first_tile <= blockIdx.x
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (jobs[mid * 8 + 6] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    sjob = lo;
+  }
+  __syncthreads();
+  const int64_t* j = jobs + sjob * 8;
+  const int A = (int)j[3], B = (int)j[4], T = (int)j[5];
+  const int local = (int)(blockIdx.x - j[6]);
+  const int tb = (B + 31) / 32;
+  const int a0 = (local / tb) * 32, b0 = (local % tb) * 32;
+  if (j[7] == INSAR_BF16) weight_prep_pair_tile<bf16_t>((const float*)j[0], (bf16_t*)j[1], (bf16_t*)j[2], A, B, T, a0, b0, tile);
+  else weight_prep_pair_tile<float>((const float*)j[0], (float*)j[1], (float*)j[2], A, B, T, a0, b0, tile);
+}
+
+extern "C" int insar_weight_prep_pair_batch(const int64_t* jobs, int32_t njobs, int64_t total_tiles, void* stream) {
+  if (!jobs || njobs < 1 || total_tiles < 1 || total_tiles > 0x7fffffffLL) INSAR_FAIL(INSAR_E_ARG, "insar_weight_prep_pair_batch: bad arguments");
+  hipLaunchKernelGGL(weight_prep_pair_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, jobs, njobs);
+  INSAR_CHECK_LAUNCH("insar_weight_prep_pair_batch");
+  return INSAR_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // segmented column sums of partial slabs: out[s][c] (+)= sum_{r in split} part[s][r][c]
 // grid = (col blocks of 64, row splits, segments); block = 64 cols x 4 row lanes.

@@ -195,13 +195,16 @@ class WeightSet:
         if self._jobs is None or ptrs != self._ptrs:
             rows, tile0 = [], 0
             for w in self.weights:
-                for which in ("fwd", "dgrad"):
-                    T, N, K, st, sn, sk = w._spec[which]
-                    rows.append([w.master().data_ptr(), w._buf[which].data_ptr(), T, N, K, st, sn, sk, tile0, self.ctx.code])
-                    tile0 += T * ((N + 31) // 32) * ((K + 31) // 32)
+                # master in[a][b][T]: Conv2d (Co,Ci,3,3): out_ab = forward form, out_ba = dgrad form;
+                # ConvTranspose2d (Ci,Co,2,2): out_ab = dgrad form, out_ba = forward form
+                a, b = w.param.shape[0], w.param.shape[1]
+                T = w.param.shape[2] * w.param.shape[3]
+                oab, oba = (w._buf["fwd"], w._buf["dgrad"]) if w.kind == "conv3" else (w._buf["dgrad"], w._buf["fwd"])
+                rows.append([w.master().data_ptr(), oab.data_ptr(), oba.data_ptr(), a, b, T, tile0, self.ctx.code])
+                tile0 += ((a + 31) // 32) * ((b + 31) // 32)
             self._jobs = torch.tensor(rows, dtype=torch.int64).to(self.ctx.device)
             self._ptrs, self._total = ptrs, tile0
-        call("insar_weight_prep_batch", ptr(self._jobs), self._jobs.shape[0], self._total, _lib.stream_ptr())
+        call("insar_weight_prep_pair_batch", ptr(self._jobs), self._jobs.shape[0], self._total, _lib.stream_ptr())
         for w in self.weights:
             w._key["fwd"] = w._key["dgrad"] = w.key()
 
@@ -264,6 +267,15 @@ def _conv3x3_flat(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[to
         PROFILER.run(tag, flops, lambda: call("insar_conv3x3_flat", x.ref, y.ref, ptr(w), flip, ptr(stats), _lib.stream_ptr()))
         return
     call("insar_conv3x3_flat", x.ref, y.ref, ptr(w), flip, ptr(stats), _lib.stream_ptr())
+
+
+def _conv3x3_c64(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[torch.Tensor]) -> None:
+    if PROFILER is not None:
+        flops = 2.0 * x.B * x.H * x.W * 64 * 64 * 9
+        PROFILER.run("conv3x3_c64_kernel<2>", flops,
+                     lambda: call("insar_conv3x3_c64", x.ref, y.ref, ptr(w), flip, ptr(stats), _lib.stream_ptr()))
+        return
+    call("insar_conv3x3_c64", x.ref, y.ref, ptr(w), flip, ptr(stats), _lib.stream_ptr())
 
 
 def _launch_wgrad(d: InsarWgrad, M: int, cin: int, cout: int, ntaps: int, code: int) -> None:
@@ -349,17 +361,22 @@ class ConvBN:
         self.M = B * H * W
         self.y = Act.alloc(B, H, W, self.cout, ctx.dtype, ctx.device)           # raw conv output (no bias)
         # large grids: flat-padded kernel (A rows shared by the three dx taps); else the per-tap implicit GEMM
-        self.flat_fwd = (not self.small) and bool(call("insar_conv3x3_flat_ok", x.ref, self.cout))
-        self.flat_bwd = (not self.small) and bool(call("insar_conv3x3_flat_ok", x.ref, self.cin))
+        # 64 -> 64 channels in bf16: persistent register-weight kernel (forward and input gradient)
+        self.c64 = (not self.small) and bool(call("insar_conv3x3_c64_ok", x.ref, self.cout)) \
+            and os.environ.get("INSAR_C64", "1") != "0"
+        self.flat_fwd = (not self.small) and not self.c64 and bool(call("insar_conv3x3_flat_ok", x.ref, self.cout))
+        self.flat_bwd = (not self.small) and not self.c64 and bool(call("insar_conv3x3_flat_ok", x.ref, self.cin))
         if self.small:
             self.stat_rows = B * H
+        elif self.c64:
+            self.stat_rows = call("insar_conv3x3_c64_rows", x.ref)
         elif self.flat_fwd:
             self.stat_rows = call("insar_conv3x3_flat_num_mtiles", x.ref)
         else:
             self.stat_rows = call("insar_igemm_num_mtiles", self.M, self.cout)
         self.stats = ctx.f32(self.stat_rows, 2, self.cout)
         # BN partial sums: slabs with many rows are folded to <= 64 rows first, bn_finalize folds the rest
-        self.stat_rps = 0 if self.stat_rows <= 128 else max(64, -(-self.stat_rows // 64))
+        self.stat_rps = 0 if self.stat_rows <= 256 else max(64, -(-self.stat_rows // 64))
         self.fold_rows = self.stat_rows if not self.stat_rps else -(-self.stat_rows // self.stat_rps)
         self.sums = ctx.f32(self.fold_rows, 2, self.cout) if self.stat_rps else self.stats
         self.scale, self.shift = ctx.f32(self.cout), ctx.f32(self.cout)
@@ -378,6 +395,8 @@ class ConvBN:
         if self.small:
             w = self.conv.weight.detach()
             call("insar_conv3x3_small_fwd", self.x.ref, ptr(w), self.y.ref, ptr(self.stats) if training else 0, s)
+        elif self.c64:
+            _conv3x3_c64(self.x, self.y, self.w.fwd(), 0, self.stats if training else None)
         elif self.flat_fwd:
             _conv3x3_flat(self.x, self.y, self.w.fwd(), 0, self.stats if training else None)
         else:
@@ -442,7 +461,9 @@ class ConvBN:
         if dx is not None:
             if self.small:
                 raise _lib.InsarError(f"{self.name}: input gradient of the direct first-layer conv is not provided")
-            if self.flat_bwd:
+            if self.c64:
+                _conv3x3_c64(self.dy, dx, self.w.dgrad(), 1, None)
+            elif self.flat_bwd:
                 _conv3x3_flat(self.dy, dx, self.w.dgrad(), 1, None)
             else:
                 _igemm(self.dy, dx, self.w.dgrad(), self.cin, H, W, 1, _TAPS3_DGRAD, 0)

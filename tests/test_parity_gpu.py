@@ -147,6 +147,75 @@ def test_conv3x3_flat_against_float64(dev, dtype, cin, cout, shape):
     assert _halo_abs(dxa) == 0.0
 
 
+@pytest.mark.parametrize("shape", [
+    (2, 64, 40, 56),       # several tiles, short rows
+    (1, 64, 33, 300),      # rows longer than a tile
+    (3, 64, 30, 30),       # tiles straddle images
+    (1, 64, 16, 16),       # fewer pixels than two tiles
+    (2, 64, 256, 256),     # the full-resolution level: one work-group walks many tiles, ring wraps
+])
+def test_conv3x3_c64_against_float64(dev, shape):
+    """The persistent 64 -> 64 channel kernel (weights in registers, rolling LDS window), forward with
+    BatchNorm partial sums and flipped = input gradient, against float64 on the kernel's own operands."""
+    from insar_unet_ca_amd import _lib, engine
+    from insar_unet_ca_amd._lib import call, ptr
+    dtype = torch.bfloat16
+    ctx = engine.Ctx(dev, dtype)
+    b, _, h, w = shape
+    xa = _act_from(cf.make_input(shape), dtype, dev)
+    assert call("insar_conv3x3_c64_ok", xa.ref, 64) == 1
+    ya = engine.Act.alloc(b, h, w, 64, dtype, dev)
+    p = torch.nn.Parameter(cf.fill_tensor("weight", (64, 64, 3, 3), 11).to(dev))
+    gw = engine.GemmWeight(ctx, p, "conv3")
+    rows = call("insar_conv3x3_c64_rows", xa.ref)
+    stats = torch.full((rows, 2, 64), float("nan"), device=dev)
+    call("insar_conv3x3_c64", xa.ref, ya.ref, ptr(gw.fwd()), 0, ptr(stats), _lib.stream_ptr())
+    xr = xa.nchw().cpu().double()
+    wr = gw.fwd().float().cpu().reshape(3, 3, 64, 64).permute(2, 3, 0, 1).double()
+    assert max_rel(ya.nchw(), F.conv2d(xr, wr, padding=1)) <= 6e-3      # bf16 output rounding only
+    assert _halo_abs(ya) == 0.0
+    got = ya.nchw().double().cpu()
+    assert max_rel(stats.sum(0)[0], got.sum((0, 2, 3))) <= 1e-4
+    assert max_rel(stats.sum(0)[1], (got ** 2).sum((0, 2, 3))) <= 1e-4
+    ga = _act_from(cf.make_grad((b, 64, h, w)), dtype, dev)
+    dxa = engine.Act.alloc(b, h, w, 64, dtype, dev)
+    call("insar_conv3x3_c64", ga.ref, dxa.ref, ptr(gw.dgrad()), 1, 0, _lib.stream_ptr())
+    assert max_rel(dxa.nchw(), F.conv_transpose2d(ga.nchw().cpu().double(), wr, padding=1)) <= 6e-3
+    assert _halo_abs(dxa) == 0.0
+    # a channel slice of a wider buffer as input and as output (the concat buffers)
+    wide = engine.Act.alloc(b, h, w, 128, dtype, dev)
+    engine.pack_input(cf.make_input(shape).to(dev), wide.slice(64, 64))
+    out = engine.Act.alloc(b, h, w, 128, dtype, dev)
+    call("insar_conv3x3_c64", wide.slice(64, 64).ref, out.slice(0, 64).ref, ptr(gw.fwd()), 0, 0, _lib.stream_ptr())
+    assert torch.equal(out.slice(0, 64).nchw(), ya.nchw())
+    assert float(out.slice(64, 64).nchw().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_weight_relayout_single_and_batched(dev, dtype):
+    """GEMM-operand forms of Conv2d / ConvTranspose2d weights: the per-weight kernel and the one-launch
+    paired kernel (both forms from one read) give exactly the permutations of the fp32 master."""
+    from insar_unet_ca_amd import engine
+    ctx = engine.Ctx(dev, dtype)
+    shapes = [("conv3", (128, 64, 3, 3)), ("conv3", (64, 192, 3, 3)), ("convT", (128, 64, 2, 2)), ("convT", (64, 64, 2, 2))]
+    params = [torch.nn.Parameter(cf.fill_tensor("weight", shp, 3 + i).to(dev)) for i, (_, shp) in enumerate(shapes)]
+    single = [engine.GemmWeight(ctx, p, kind) for p, (kind, _) in zip(params, shapes)]
+    batched = [engine.GemmWeight(ctx, p, kind) for p, (kind, _) in zip(params, shapes)]
+    engine.WeightSet(ctx, batched).refresh()
+    for (kind, shp), p, a, b in zip(shapes, params, single, batched):
+        w = p.detach().to(dtype)
+        if kind == "conv3":     # (Co,Ci,3,3) -> [tap][co][ci] and [tap][ci][co]
+            fwd = w.permute(2, 3, 0, 1).reshape(9, shp[0], shp[1])
+            dgr = w.permute(2, 3, 1, 0).reshape(9, shp[1], shp[0])
+        else:                   # (Ci,Co,2,2) -> [tap][co][ci] and [tap][ci][co]
+            fwd = w.permute(2, 3, 1, 0).reshape(4, shp[1], shp[0])
+            dgr = w.permute(2, 3, 0, 1).reshape(4, shp[0], shp[1])
+        for got in (a.fwd(), b._buf["fwd"]):
+            assert torch.equal(got, fwd), (kind, shp)
+        for got in (a.dgrad(), b._buf["dgrad"]):
+            assert torch.equal(got, dgr), (kind, shp)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_transpose_against_golden_and_float64(dev, dtype, golden):
     from insar_unet_ca_amd import engine
