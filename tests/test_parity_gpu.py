@@ -600,6 +600,24 @@ def test_unet_bf16_against_golden(dev, golden, tag, shape):
     assert abs(float(net.outc.weight.grad.norm()) - nrm) / nrm <= 0.1
 
 
+def test_unet_bf16_generic_position(dev, golden):
+    """bf16 forward on the generic-position fixture G3r, gated at torch's OWN bf16 error on the same fixture
+    (oracle, CPU, measured in-container: all-bf16 8.5e-2 max-rel / 98.2 % arg-max agreement, autocast
+    7.0e-2 / 98.4 %; SURVEY 8d's 3e-2 / 99 % probe was taken on torch-default-init weights, which are 3x
+    smaller). The HIP bf16 path (bf16 storage, fp32 accumulation and BN statistics) measures 5.6e-2 / 98.5 %."""
+    import insar_unet_ca_amd as iu
+    g = golden("g3r_unet_random")
+    net = iu.UNet(2, 2, True, compute_dtype=torch.bfloat16)
+    net.load_state_dict(cf.fill_state_dict_random(net.state_dict(), seed=7))
+    net = net.to(dev).train()
+    logits = net(cf.make_input_random((2, 2, 64, 64), seed=11).to(dev))
+    ref = torch.from_numpy(g["b2_64_train/logits/full"]).reshape(2, 2, 64, 64)
+    err = max_rel(logits, ref)
+    agree = (logits.argmax(1).cpu() == ref.argmax(1)).float().mean().item()
+    print(f"bf16 vs reference on G3r: max-rel {err:.3e}, arg-max agreement {agree:.4f}")
+    assert err <= 8.5e-2 and agree >= 0.98
+
+
 # ------------------------------------------------------------------------------------------------
 # loss / metrics / optimizer entry points
 # ------------------------------------------------------------------------------------------------
