@@ -1,11 +1,12 @@
 """insar_unet_ca_amd — MI355X-native U-Net-CA training hot path (drop-in for
 Createroner/InSAR-Unet-CA's Unet-ChannalAttention.py model/loss/optimizer entry points)."""
 from ._lib import InsarError, LIB_PATH  # noqa: F401
+from .data import ShardedSampler, SyntheticTiles, VOCSegDataset, make_loader, reference_transforms  # noqa: F401
 from .loss import CrossEntropyLoss, DiceCELoss, DiceLoss  # noqa: F401
 from .modules import DoubleConv, MaxPool2d, SELayer, UNet  # noqa: F401
 from .optim import Adam  # noqa: F401
-from .train import compute_metrics, train_model, validate_model  # noqa: F401
-from .train import compute_metrics, train_model, validate_model  # noqa: F401
+from .train import compute_metrics, save_history, train_model, validate_model  # noqa: F401
 
 __all__ = ["UNet", "DoubleConv", "SELayer", "MaxPool2d", "CrossEntropyLoss", "DiceLoss", "DiceCELoss", "Adam",
-           "compute_metrics", "train_model", "validate_model", "compute_metrics", "train_model", "validate_model", "InsarError", "LIB_PATH"]
+           "compute_metrics", "train_model", "validate_model", "save_history", "VOCSegDataset", "SyntheticTiles",
+           "ShardedSampler", "make_loader", "reference_transforms", "InsarError", "LIB_PATH"]

@@ -61,3 +61,98 @@ class SyntheticTiles(torch.utils.data.Dataset):
         seed0 = HELDOUT_SEED0 if self.heldout else TRAIN_SEED0
         img, lab = make_tile(seed0 + self.offset + idx, self.size, self.channels)
         return torch.from_numpy(img), torch.from_numpy(lab)
+
+
+# ---- the reference's on-disk format ----------------------------------------------
+def reference_transforms(image_size: int):
+    """The reference's `data_transforms` (Unet-ChannalAttention.py:428-432) without torchvision:
+    Resize((S,S)) on a PIL image is PIL's bilinear `Image.resize` (torchvision calls exactly that for PIL
+    inputs), ToTensor is uint8 -> float32 / 255 with a leading channel axis, Normalize(0.5, 0.5) is
+    (x - 0.5) / 0.5. Returns a callable PIL 'L' image -> float32 tensor [1, S, S] in [-1, 1]."""
+    from PIL import Image
+
+    def apply(img):
+        img = img.resize((image_size, image_size), Image.BILINEAR)
+        x = torch.from_numpy(np.asarray(img, dtype=np.uint8).astype(np.float32) / 255.0)
+        return ((x - 0.5) / 0.5).unsqueeze(0)
+
+    return apply
+
+
+class VOCSegDataset(torch.utils.data.Dataset):
+    """Reader for the reference's VOC-layout tile sets, same constructor and item contract as
+    `VOCSegDataset` (Unet-ChannalAttention.py:167-212):
+
+        voc_root/JPEGImages/<id>.jpg            grey-level tile          -> img  float32 [1, S, S]
+        voc_root/SegmentationClass/<id>.png     mask, 255 = feature      -> mask int64 [S, S] in {0, 1}
+        voc_root/ImageSets/Segmentation/<image_set>.txt   one id per line
+
+    The mask goes through a nearest-neighbour resize, ToTensor (/255) and `.long()` in the reference
+    (:201-210), i.e. floor(px / 255): 255 -> 1, every other grey level -> 0. `transforms` defaults to
+    `reference_transforms(image_size)`; pass the reference's own torchvision Compose if torchvision is
+    installed — anything mapping a PIL 'L' image to a tensor works."""
+
+    def __init__(self, voc_root: str, image_size: int, image_set: str = "train", transforms=None):
+        import os
+        self.voc_root, self.image_size = voc_root, image_size
+        self.transforms = transforms if transforms is not None else reference_transforms(image_size)
+        self.image_dir = os.path.join(voc_root, "JPEGImages")
+        self.mask_dir = os.path.join(voc_root, "SegmentationClass")
+        self.image_set_path = os.path.join(voc_root, "ImageSets", "Segmentation", f"{image_set}.txt")
+        if not os.path.exists(self.image_set_path):
+            raise FileNotFoundError(f"ImageSets file not found: {self.image_set_path}")
+        with open(self.image_set_path, "r") as f:
+            self.ids = [line.strip() for line in f.readlines()]
+
+    def __len__(self):
+        return len(self.ids)
+
+    def __getitem__(self, idx: int):
+        import os
+        from PIL import Image
+        img_id = self.ids[idx]
+        img = Image.open(os.path.join(self.image_dir, f"{img_id}.jpg")).convert("L")
+        mask = Image.open(os.path.join(self.mask_dir, f"{img_id}.png")).convert("L")
+        img = self.transforms(img)
+        mask = mask.resize((self.image_size, self.image_size), Image.NEAREST)
+        mask = torch.from_numpy((np.asarray(mask, dtype=np.uint8) // 255).astype(np.int64))
+        return img, mask
+
+
+class ShardedSampler(torch.utils.data.Sampler):
+    """Data-parallel sampler: every rank draws the same seeded permutation of the dataset per
+    epoch and keeps the indices `rank::world` of it, padded by wrap-around so that all ranks take the same
+    number of steps (the gradient all-reduce needs that). `set_epoch(e)` reshuffles; numpy PCG64, no torch RNG."""
+
+    def __init__(self, length: int, rank: int = 0, world: int = 1, shuffle: bool = True, seed: int = 0):
+        if not 0 <= rank < world:
+            raise ValueError(f"rank {rank} outside world of {world}")
+        self.length, self.rank, self.world, self.shuffle, self.seed = length, rank, world, shuffle, seed
+        self.epoch = 0
+        self.per_rank = -(-length // world)
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = epoch
+
+    def __len__(self):
+        return self.per_rank
+
+    def __iter__(self):
+        if self.shuffle:
+            order = np.random.Generator(np.random.PCG64([self.seed, self.epoch])).permutation(self.length)
+        else:
+            order = np.arange(self.length)
+        total = self.per_rank * self.world
+        if total > self.length:
+            order = np.resize(order, total)            # cyclic wrap-around padding
+        return iter(order[self.rank:total:self.world].tolist())
+
+
+def make_loader(dataset, batch_size: int, rank: int = 0, world: int = 1, shuffle: bool = True, seed: int = 0,
+                num_workers: int = 0, drop_last: bool = False):
+    """DataLoader as the reference builds it (:436-451: pinned memory, worker processes) with the rank's
+    shard of the data; `.to(device, non_blocking=True)` in the training loop then overlaps the H2D copy."""
+    sampler = ShardedSampler(len(dataset), rank, world, shuffle, seed)
+    return torch.utils.data.DataLoader(dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers,
+                                       pin_memory=torch.cuda.is_available(), drop_last=drop_last,
+                                       persistent_workers=num_workers > 0)

@@ -103,6 +103,16 @@ def validate_model(model, dataloader, criterion, device, num_classes: int = 2, v
     return res
 
 
+def save_history(history: List[Dict[str, Any]], path: str) -> None:
+    """The reference's metrics file (:472-487): a JSON list with one dict per epoch (`epoch`, `train_*`,
+    `val_*` keys), tensors converted to Python floats, indent 4."""
+    import json
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    rows = [{k: (v.item() if isinstance(v, torch.Tensor) else v) for k, v in rec.items()} for rec in history]
+    with open(path, "w") as f:
+        json.dump(rows, f, indent=4)
+
+
 def train_model(model, train_dataloader, val_dataloader, criterion, optimizer, device, num_epochs: int = 25,
                 num_classes: int = 2, model_save_path: Optional[str] = None, verbose: bool = True) -> List[Dict[str, Any]]:
     """train_model (:321-399): returns the per-epoch history (train_* / val_* keys of the reference);

@@ -861,3 +861,32 @@ def test_train_and_validate_loop_mirrors_reference(dev, golden, tmp_path):
     np.testing.assert_allclose([ours[k] for k in ref], [ref[k] for k in ref], atol=1e-12)
     v = validate_model(net, val_dl, iu.CrossEntropyLoss(ignore_index=255), dev, verbose=False)
     assert abs(v["val_miou"] - ours["miou"]) < 1e-12     # one batch: weighted mean == the batch value
+
+
+def test_train_loop_over_the_voc_reader(dev, tmp_path):
+    """End to end on the reference's on-disk format (8f rank 2): VOC-layout tiles -> VOCSegDataset ->
+    sharded loader -> train_model on the HIP path with the reference's in_channels=1 model (:464)."""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd.data import make_tile
+    root = str(tmp_path / "voc")
+    for d in ("JPEGImages", "SegmentationClass", "ImageSets/Segmentation"):
+        (tmp_path / "voc" / d).mkdir(parents=True)
+    ids = [f"tile_{i:03d}" for i in range(12)]
+    for i, name in enumerate(ids):
+        img, lab = make_tile(1000 + i, 32, channels=1)
+        Image.fromarray(((img[0] * 0.5 + 0.5) * 255).astype(np.uint8), "L").save(f"{root}/JPEGImages/{name}.jpg", quality=95)
+        Image.fromarray((lab * 255).astype(np.uint8), "L").save(f"{root}/SegmentationClass/{name}.png")
+    open(f"{root}/ImageSets/Segmentation/train.txt", "w").write("\n".join(ids[:8]) + "\n")
+    open(f"{root}/ImageSets/Segmentation/val.txt", "w").write("\n".join(ids[8:]) + "\n")
+    train_dl = iu.make_loader(iu.VOCSegDataset(root, 32, "train"), batch_size=4, shuffle=True, seed=1)
+    val_dl = iu.make_loader(iu.VOCSegDataset(root, 32, "val"), batch_size=4, shuffle=False)
+    torch.manual_seed(0)
+    net = iu.UNet(in_channels=1, num_classes=2, use_se=True)
+    hist = iu.train_model(net, train_dl, val_dl, iu.CrossEntropyLoss(ignore_index=255), iu.Adam(net.parameters(), lr=1e-3),
+                          dev, num_epochs=2, model_save_path=str(tmp_path / "best.pth"), verbose=False)
+    assert len(hist) == 2 and hist[1]["train_loss"] < hist[0]["train_loss"]
+    assert all(np.isfinite(v) for rec in hist for v in rec.values())
+    iu.save_history(hist, str(tmp_path / "metrics" / "history.json"))
+    assert (tmp_path / "best.pth").exists() and (tmp_path / "metrics" / "history.json").exists()
