@@ -196,11 +196,14 @@ def main() -> int:
                     "kernel": dom_tag, "bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": traffic,
                     "flop_per_launch": round(dom["flops"] / dom["launches"], 1),
+                    "algorithmic_bytes_per_launch": round(dom.get("bytes", 0.0) / dom["launches"], 1) or None,
                     "avg_launch_us": round(dom["avg_us"], 2), "launches": dom["launches"],
                     "share_of_step": round(dom["ms"] / (1e3 * timed_elapsed), 4),
-                    "measured": "HIP events around each launch on the launch stream, second pass of the same %d steps "
-                                "(%.2f ms/step with events vs %.2f ms/step in the timed region); traffic = rocprofv3 "
-                                "PMC (2*FETCH_SIZE + WRITE_SIZE) per launch from profiles/r01_pmc_traffic.json" %
+                    "measured": "HIP events around each launch on the launch stream, in a second pass of the same %d "
+                                "steps run on ONE stream (as with INSAR_SIDE_STREAM=0: per-kernel durations without "
+                                "the weight-gradient overlap; %.2f ms/step with events vs %.2f ms/step in the timed "
+                                "region); compare profiles/r01_bench_kernel_stats_single_stream.csv; traffic = "
+                                "rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per launch from profiles/r01_pmc_traffic.json" %
                                 (args.steps, 1e3 * timed_elapsed / args.steps, ms),
                 }
             gemm_ms = sum(v["ms"] for v in summ.values())

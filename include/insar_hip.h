@@ -101,6 +101,7 @@ typedef struct InsarIgemm {
  * (the tile height, 128 or 256 pixels, is chosen from M and N so that the grid fills the 256 CUs). */
 int insar_igemm_num_mtiles(int64_t M, int32_t N);
 int insar_igemm_tile_rows(int64_t M, int32_t N);
+int insar_igemm_tile_cols(int64_t M, int32_t N);   /* 128 or 64 output channels per tile */
 int insar_igemm(const InsarIgemm* d, void* stream);
 
 /* ---- 3x3 / stride-1 convolution over the flat padded pixel space (MFMA) -------------------------------

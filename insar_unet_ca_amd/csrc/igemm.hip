@@ -290,7 +290,17 @@ static inline int igemm_bm_for(long long M, int N) {
   const long long tiles256 = ((M + 255) / 256) * (N / bn);
   return tiles256 >= 256 ? 256 : 128;
 }
+// Output-channel tile: 128 wide where N allows, except on grids so small that 128x128 tiles would leave one
+// 4-wave work-group per CU (the 16x16 level): 128x64 tiles double the work-groups (two per CU, two waves
+// per SIMD to hide each other's LDS and barrier latency).
+static inline int igemm_bn_for(long long M, int N) {
+  if (N % 128) return 64;
+  if (igemm_bm_for(M, N) == 256) return 128;
+  const long long tiles = ((M + 127) / 128) * (N / 128);
+  return tiles <= 256 ? 64 : 128;
+}
 extern "C" int insar_igemm_tile_rows(int64_t M, int32_t N) { return igemm_bm_for(M, N); }
+extern "C" int insar_igemm_tile_cols(int64_t M, int32_t N) { return igemm_bn_for(M, N); }
 extern "C" int insar_igemm_num_mtiles(int64_t M, int32_t N) {
   const int bm = igemm_bm_for(M, N);
   return (int)((M + bm - 1) / bm);
@@ -352,7 +362,7 @@ extern "C" int insar_igemm(const InsarIgemm* d, void* stream) {
   a.kc_per_tap = K / bke;
   for (int t = 0; t < 12; ++t) a.tapoff[t] = t < d->ntaps ? (d->dy[t] * (d->x.W + 2) + d->dx[t]) * d->x.C : 0;
   hipStream_t s = (hipStream_t)stream;
-  const bool wide = (d->N % 128) == 0;
+  const bool wide = igemm_bn_for(a.M, d->N) == 128;
   const bool big = igemm_bm_for(a.M, d->N) == 256;
   if (d->x.dtype == INSAR_BF16) {
     if (big) return wide ? launch_igemm<bf16_t, 256, 128, 3>(a, s) : launch_igemm<bf16_t, 256, 64, 3>(a, s);

@@ -359,15 +359,15 @@ extern "C" int insar_colsum_partial(const float* part, float* out, int64_t rows,
 // sums[0][c] = sum y_raw, sums[1][c] = sum y_raw^2 over `count` pixels (y_raw = conv w/o bias).
 // ---------------------------------------------------------------------------------------------
 __global__ void bn_finalize_kernel(InsarBnFinalize d) {
-  // 64 channels per block, 4 row lanes per channel (threadIdx = lane*64 + channel)
-  __shared__ double fold[2][4][64];
+  // 64 channels per block, 8 row lanes per channel (threadIdx = lane*64 + channel)
+  __shared__ double fold[2][8][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   if (c == 0 && rl == 0 && d.training && d.num_batches_tracked) *d.num_batches_tracked += 1;
   if (d.training) {
     double s1 = 0.0, s2 = 0.0;
     if (c < d.C)
-      for (int64_t r = rl; r < d.rows; r += 4) {     // fold the remaining partial rows: [rows][2][C]
+      for (int64_t r = rl; r < d.rows; r += 8) {     // fold the remaining partial rows: [rows][2][C]
         s1 += (double)d.part[(r * 2 + 0) * d.C + c];
         s2 += (double)d.part[(r * 2 + 1) * d.C + c];
       }
@@ -379,8 +379,10 @@ __global__ void bn_finalize_kernel(InsarBnFinalize d) {
   float mean_raw, invstd;
   if (d.training) {
     const double n = (double)d.count;
-    const double s1 = (fold[0][0][cl] + fold[0][1][cl]) + (fold[0][2][cl] + fold[0][3][cl]);
-    const double s2 = (fold[1][0][cl] + fold[1][1][cl]) + (fold[1][2][cl] + fold[1][3][cl]);
+    const double s1 = ((fold[0][0][cl] + fold[0][1][cl]) + (fold[0][2][cl] + fold[0][3][cl])) +
+                      ((fold[0][4][cl] + fold[0][5][cl]) + (fold[0][6][cl] + fold[0][7][cl]));
+    const double s2 = ((fold[1][0][cl] + fold[1][1][cl]) + (fold[1][2][cl] + fold[1][3][cl])) +
+                      ((fold[1][4][cl] + fold[1][5][cl]) + (fold[1][6][cl] + fold[1][7][cl]));
     const double m = s1 / n;
     double var = s2 / n - m * m;
     if (var < 0) var = 0;
@@ -409,7 +411,7 @@ extern "C" int insar_bn_finalize(const InsarBnFinalize* d, void* stream) {
   if (d->training && (!d->part || d->count < 1 || d->rows < 1 || d->rows > 4096))
     INSAR_FAIL(INSAR_E_ARG, "insar_bn_finalize: training needs 1..4096 rows of partial sums");
   if (!d->training && (!d->running_mean || !d->running_var)) INSAR_FAIL(INSAR_E_ARG, "insar_bn_finalize: eval needs running stats");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->C + 63) / 64), dim3(256), 0, (hipStream_t)stream, *d);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->C + 63) / 64), dim3(512), 0, (hipStream_t)stream, *d);
   INSAR_CHECK_LAUNCH("insar_bn_finalize");
   return INSAR_OK;
 }

@@ -216,20 +216,20 @@ class KernelTimer:
     def __init__(self):
         self.records: Dict[str, list] = {}
 
-    def run(self, tag: str, flops: float, fn) -> None:
+    def run(self, tag: str, flops: float, fn, nbytes: float = 0.0) -> None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
-        self.records.setdefault(tag, []).append((e0, e1, flops))
+        self.records.setdefault(tag, []).append((e0, e1, flops, nbytes))
 
     def summary(self) -> Dict[str, dict]:
         torch.cuda.synchronize()
         out = {}
         for tag, recs in self.records.items():
-            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
-            fl = sum(f for _, _, f in recs)
-            out[tag] = {"launches": len(recs), "ms": ms, "flops": fl,
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+            fl = sum(r[2] for r in recs)
+            out[tag] = {"launches": len(recs), "ms": ms, "flops": fl, "bytes": sum(r[3] for r in recs),
                         "avg_us": 1e3 * ms / max(len(recs), 1), "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
         return out
 
@@ -254,8 +254,10 @@ def _igemm(x: Act, y: Act, w: torch.Tensor, N: int, Ho: int, Wo: int, stride: in
         flops = 2.0 * x.B * Ho * Wo * N * x.c_len * len(taps)
         bm = call("insar_igemm_tile_rows", x.B * Ho * Wo, N)
         tag = "igemm_kernel<%s, %d, %d, %d>" % ("float" if x.code == _lib.F32 else "bf16_t", bm,
-                                                128 if N % 128 == 0 else 64, 3 if bm == 256 else 2)
-        PROFILER.run(tag, flops, lambda: call("insar_igemm", C.byref(d), _lib.stream_ptr()))
+                                                call("insar_igemm_tile_cols", x.B * Ho * Wo, N), 3 if bm == 256 else 2)
+        es = 2 if x.code == _lib.BF16 else 4      # operands each read once, output written once
+        nbytes = es * (x.B * x.H * x.W * x.c_len + y.B * y.H * y.W * y.c_len + w.numel())
+        PROFILER.run(tag, flops, lambda: call("insar_igemm", C.byref(d), _lib.stream_ptr()), nbytes)
         return
     call("insar_igemm", C.byref(d), _lib.stream_ptr())
 

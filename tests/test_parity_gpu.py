@@ -890,3 +890,51 @@ def test_train_loop_over_the_voc_reader(dev, tmp_path):
     assert all(np.isfinite(v) for rec in hist for v in rec.values())
     iu.save_history(hist, str(tmp_path / "metrics" / "history.json"))
     assert (tmp_path / "best.pth").exists() and (tmp_path / "metrics" / "history.json").exists()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_miou_parity_task(dev, dtype):
+    """north_star's mIoU clause at the resolution the task allows. tests/golden/g8b_miou_parity.json holds the
+    oracle's validation-mIoU curves on a 64x64 synthetic task (256 train / 256 held-out tiles, 12 epochs, same
+    tiles, order and initial weights as here, tools/miou_parity.py) for the plain run and for two runs with
+    1e-6 relative noise on the training inputs: their last-4-epoch means are 0.549 / 0.581 / 0.569, i.e. the
+    reference algorithm itself is only reproducible to ~3 pt on this metric (Adam + ReLU/BN chaos, 3-8 %
+    positive pixels). The HIP path must land inside that band widened by 4 pt (round 1 on MI355X: fp32 0.580,
+    bf16 0.596) and reach the oracle's validation loss."""
+    import json
+    import os
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd.data import make_batch
+    from insar_unet_ca_amd.train import confusion_counts, metrics_from_counts
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g8b_miou_parity.json")))["runs"]
+    oracle = [float(np.mean(ref[k]["val_miou"][-4:])) for k in ("oracle_p0", "oracle_p1", "oracle_p2")]
+    batch, ntrain, nval, epochs = 8, 256, 256, 12
+    train = [tuple(t.to(dev) for t in make_batch(i * batch, batch, 64)) for i in range(ntrain // batch)]
+    val = [tuple(t.to(dev) for t in make_batch(i * batch, batch, 64, heldout=True)) for i in range(nval // batch)]
+    net = iu.UNet(2, 2, True, compute_dtype=dtype)
+    net.load_state_dict(cf.fill_state_dict_random(net.state_dict(), seed=7))
+    net = net.to(dev)
+    crit, opt = iu.CrossEntropyLoss(ignore_index=255), iu.Adam(net.parameters(), lr=3e-4)
+    rng = np.random.Generator(np.random.PCG64(4242))
+    curve, vloss = [], []
+    for ep in range(epochs):
+        net.train()
+        for bi in rng.permutation(len(train)):
+            x, y = train[bi]
+            opt.zero_grad()
+            crit(net(x), y).backward()
+            opt.step()
+        net.eval()
+        miou, loss = 0.0, 0.0
+        with torch.no_grad():
+            for x, y in val:
+                lg = net(x)
+                c = confusion_counts(lg, y, 2).cpu().numpy()
+                miou += metrics_from_counts(c[0], c[1], c[2])["miou"] * batch
+                loss += float(crit(lg, y)) * batch
+        curve.append(miou / nval)
+        vloss.append(loss / nval)
+    got = float(np.mean(curve[-4:]))
+    print(f"{dtype}: val mIoU mean(last 4) {got:.4f} (oracle runs {oracle}), val loss {vloss[-1]:.4f}")
+    assert min(oracle) - 0.04 <= got <= max(oracle) + 0.04
+    assert vloss[-1] <= max(ref[k]["val_loss"][-1] for k in ("oracle_p0", "oracle_p1", "oracle_p2")) + 0.02

@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--perturb", type=float, default=0.0, help="relative input noise (oracle sensitivity study)")
     ap.add_argument("--pseed", type=int, default=1)
+    ap.add_argument("--init", default="closed-form", choices=["closed-form", "random"],
+                    help="initial weights: closed-form sines (G3) or PCG64 generic position (G3r, better conditioned)")
+    ap.add_argument("--threads", type=int, default=16)
     a = ap.parse_args()
     nb, nvb = a.train // a.batch, a.val // a.batch
     train = [make_batch(i * a.batch, a.batch, a.size) for i in range(nb)]
@@ -37,8 +40,9 @@ def main():
     history = []
     t0 = time.time()
     if a.side == "oracle":
-        torch.set_num_threads(min(os.cpu_count() or 1, 16))
-        sd = cf.fill_state_dict(orc.state_dict_template(2, 2, True))
+        torch.set_num_threads(min(os.cpu_count() or 1, a.threads))
+        tmpl = orc.state_dict_template(2, 2, True)
+        sd = cf.fill_state_dict(tmpl) if a.init == "closed-form" else cf.fill_state_dict_random(tmpl, seed=7)
         state = {}
         for ep in range(a.epochs):
             order = rng.permutation(nb)
@@ -67,7 +71,8 @@ def main():
         dev = torch.device("cuda:0")
         dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
         net = iu.UNet(2, 2, True, compute_dtype=dt)
-        net.load_state_dict(cf.fill_state_dict(net.state_dict()))
+        net.load_state_dict(cf.fill_state_dict(net.state_dict()) if a.init == "closed-form"
+                            else cf.fill_state_dict_random(net.state_dict(), seed=7))
         net = net.to(dev)
         crit = iu.CrossEntropyLoss(ignore_index=255)
         opt = iu.Adam(net.parameters(), lr=a.lr)
