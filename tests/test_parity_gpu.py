@@ -900,7 +900,7 @@ def test_miou_parity_task(dev, dtype):
     1e-6 relative noise on the training inputs: their last-4-epoch means are 0.549 / 0.581 / 0.569, i.e. the
     reference algorithm itself is only reproducible to ~3 pt on this metric (Adam + ReLU/BN chaos, 3-8 %
     positive pixels). The HIP path must land inside that band widened by 4 pt (round 1 on MI355X: fp32 0.580,
-    bf16 0.596) and reach the oracle's validation loss."""
+    bf16 0.596) and reach the oracle's best validation loss (0.166-0.173; HIP 0.163 / 0.159)."""
     import json
     import os
     import insar_unet_ca_amd as iu
@@ -937,4 +937,5 @@ def test_miou_parity_task(dev, dtype):
     got = float(np.mean(curve[-4:]))
     print(f"{dtype}: val mIoU mean(last 4) {got:.4f} (oracle runs {oracle}), val loss {vloss[-1]:.4f}")
     assert min(oracle) - 0.04 <= got <= max(oracle) + 0.04
-    assert vloss[-1] <= max(ref[k]["val_loss"][-1] for k in ("oracle_p0", "oracle_p1", "oracle_p2")) + 0.02
+    # single epochs spike in every run (oracle 0.40 / 0.77, HIP 0.78): compare the best validation loss
+    assert min(vloss) <= max(min(ref[k]["val_loss"]) for k in ("oracle_p0", "oracle_p1", "oracle_p2")) + 0.01
