@@ -939,3 +939,28 @@ def test_miou_parity_task(dev, dtype):
     assert min(oracle) - 0.04 <= got <= max(oracle) + 0.04
     # single epochs spike in every run (oracle 0.40 / 0.77, HIP 0.78): compare the best validation loss
     assert min(vloss) <= max(min(ref[k]["val_loss"]) for k in ("oracle_p0", "oracle_p1", "oracle_p2")) + 0.01
+
+
+def test_boundary_input_forms(dev):
+    """forward takes contiguous or channels_last [B,Cin,H,W], fp32 or bf16 tensors; the compute
+    dtype follows `compute_dtype`, `set_compute_dtype` or an enclosing torch.autocast; logits are float32."""
+    import insar_unet_ca_amd as iu
+    net = iu.UNet(2, 2, True)
+    net.load_state_dict(cf.fill_state_dict_random(net.state_dict(), seed=7))
+    net = net.to(dev).eval()
+    x = cf.make_input_random((2, 2, 32, 48), seed=3).to(dev)
+    with torch.no_grad():
+        base = net(x)
+        assert base.dtype == torch.float32 and base.shape == (2, 2, 32, 48)
+        assert torch.equal(net(x.contiguous(memory_format=torch.channels_last)), base)
+        xb = x.to(torch.bfloat16)
+        assert torch.equal(net(xb), net(xb.float()))                   # a bf16 tensor is just its values
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            auto = net(x)
+        net.set_compute_dtype(torch.bfloat16)
+        explicit = net(x)
+        net.set_compute_dtype(None)
+        again = net(x)
+    assert auto.dtype == torch.float32 and torch.equal(auto, explicit)  # autocast == compute_dtype=bf16
+    assert torch.equal(again, base)                                     # and back to fp32, bit for bit
+    assert 0 < max_rel(explicit, base) < 0.1
