@@ -242,6 +242,32 @@ int insar_bnrelu_bwd_apply(const InsarAct* dout, const InsarAct* y, const float*
                            const float* gate, const float* coefB, const float* k1,
                            const float* k2, const InsarAct* dy, int32_t relu, void* stream);
 
+/* ---- ChannelAttentionModule (DeepLabV3-ChannelAttention.py:49-79; config 5) ---------------------------
+ * out = x * sigmoid(W2 relu(W1 avg_hw(x)) + W2 relu(W1 max_hw(x))), W1 (Cr,C), W2 (C,Cr), no biases.
+ * forward : insar_cam_pool -> insar_cam_excite -> insar_bn_relu_apply(x, ones, zeros, gate, out, relu=0)
+ * backward: insar_bnrelu_bwd_reduce(dout, x, ones, zeros, red, relu=0) -> insar_cam_bwd_coef ->
+ *           insar_bnrelu_bwd_apply(dout, x, ones, zeros, zeros, ones, gate, coefB, zeros, zeros, dx, relu=0)
+ *           -> insar_cam_scatter_max(dx, dmax, arg)
+ * pool: per part (image, rows_per_part consecutive rows) and channel the sum, the maximum and the flat
+ * index h*W+w of its first occurrence: psum/pmax/parg[B][P][C], P = ceil(H / rows_per_part). */
+typedef struct InsarCam {
+  int32_t B, H, W, C, Cr; int32_t rows;            /* rows = P of the pool slabs */
+  const float* psum; const float* pmax; const int32_t* parg;
+  const float* w1; const float* w2;
+  float* avg; float* mx; int32_t* arg;             /* [B][C] saved for backward */
+  float* ha; float* hm;                            /* [B][Cr] post-ReLU hidden activations of the two branches */
+  float* gate;                                     /* [B][C] */
+  float* coefB; float* dmax;                       /* backward: [B][C] mean-branch term /HW, max-branch term */
+  float* ws;                                       /* backward scratch: float[B*(C + 2*Cr)] */
+  float* dw1; float* dw2;
+  int32_t accumulate; int32_t _pad;
+} InsarCam;
+int insar_cam_pool(const InsarAct* x, float* psum, float* pmax, int32_t* parg, int32_t rows_per_part,
+                   void* stream);
+int insar_cam_excite(const InsarCam* d, void* stream);
+int insar_cam_bwd_coef(const InsarCam* d, const float* red /*[B][rows][2][C]*/, int32_t rows, void* stream);
+int insar_cam_scatter_max(const InsarAct* dx, const float* dmax, const int32_t* arg, void* stream);
+
 /* ---- MaxPool2d(2) (:106-109) -------------------------------------------------------------------- */
 int insar_maxpool2_fwd(const InsarAct* x, const InsarAct* y, void* stream);
 /* dx (+)= route(dy) to the first maximum in scan order (torch semantics). */

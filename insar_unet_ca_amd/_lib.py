@@ -61,6 +61,15 @@ class InsarBnSeBwd(C.Structure):
                 ("accumulate", C.c_int32), ("_pad", C.c_int32)]
 
 
+class InsarCam(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("Cr", C.c_int32),
+                ("rows", C.c_int32),
+                ("psum", C.c_void_p), ("pmax", C.c_void_p), ("parg", C.c_void_p), ("w1", C.c_void_p), ("w2", C.c_void_p),
+                ("avg", C.c_void_p), ("mx", C.c_void_p), ("arg", C.c_void_p), ("ha", C.c_void_p), ("hm", C.c_void_p),
+                ("gate", C.c_void_p), ("coefB", C.c_void_p), ("dmax", C.c_void_p), ("ws", C.c_void_p),
+                ("dw1", C.c_void_p), ("dw2", C.c_void_p), ("accumulate", C.c_int32), ("_pad", C.c_int32)]
+
+
 _P = C.c_void_p
 _I = C.c_int32
 _L = C.c_int64
@@ -100,6 +109,10 @@ _SIGNATURES = {
     "insar_bnrelu_bwd_reduce": [_AP, _AP, _P, _P, _P, _I, _I, _P],
     "insar_bnse_bwd_coef": [C.POINTER(InsarBnSeBwd), _P, _I, _P, _P, _P, _P, _I, _P],
     "insar_bnrelu_bwd_apply": [_AP, _AP, _P, _P, _P, _P, _P, _P, _P, _P, _AP, _I, _P],
+    "insar_cam_pool": [_AP, _P, _P, _P, _I, _P],
+    "insar_cam_excite": [C.POINTER(InsarCam), _P],
+    "insar_cam_bwd_coef": [C.POINTER(InsarCam), _P, _I, _P],
+    "insar_cam_scatter_max": [_AP, _P, _P, _P],
     "insar_maxpool2_fwd": [_AP, _AP, _P],
     "insar_maxpool2_bwd": [_AP, _AP, _AP, _I, _P],
     "insar_conv1x1_out_fwd": [_AP, _P, _P, _P, _I, _P],

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import InsarBnSeBwd, InsarSeFwd, call, ptr
+from ._lib import InsarBnSeBwd, InsarCam, InsarSeFwd, call, ptr
 from . import engine
 from .engine import Act, Ctx, DoubleConvPlan, GradSink, UNetPlan, pack_input, unpack_output
 
@@ -173,6 +173,97 @@ class SELayer(nn.Module):
         dt = _resolve_dtype(self)
         plan = self._plans.get((b, c, h, w, dt, x.device), lambda: _SEPlan(self, b, c, h, w, dt, x.device))
         return _SEFn.apply(plan, torch.is_grad_enabled(), x, self.fc[0].weight, self.fc[2].weight)
+
+
+# ------------------------------------------------------------------------------------------------
+# ChannelAttentionModule (config 5)
+# ------------------------------------------------------------------------------------------------
+class _CamPlan:
+    """out = x * sigmoid(MLP(avg_hw x) + MLP(max_hw x)) on a raw tensor (csrc/cam.hip)."""
+
+    def __init__(self, mod, B, Cn, H, W, dtype, device):
+        self.mod = mod
+        ctx = self.ctx = Ctx(device, dtype)
+        if Cn % 64:
+            raise _lib.InsarError(f"ChannelAttentionModule: in_channels={Cn} must be a multiple of 64 on the HIP path")
+        self.B, self.C, self.H, self.W = B, Cn, H, W
+        self.cr = mod.mlp[0].out_channels
+        self.x = Act.alloc(B, H, W, Cn, dtype, device)
+        self.out = Act.alloc(B, H, W, Cn, dtype, device)
+        self.dout = Act.alloc(B, H, W, Cn, dtype, device)
+        self.dx = Act.alloc(B, H, W, Cn, dtype, device)
+        self.rpp = engine._rows_per_part(B, H)
+        self.rows = -(-H // self.rpp)
+        self.psum, self.pmax = ctx.f32(B * self.rows, Cn), ctx.f32(B * self.rows, Cn)
+        self.parg = torch.zeros(B * self.rows, Cn, dtype=torch.int32, device=device)
+        self.avg, self.mx, self.gate = ctx.f32(B, Cn), ctx.f32(B, Cn), ctx.f32(B, Cn)
+        self.arg = torch.zeros(B, Cn, dtype=torch.int32, device=device)
+        self.ha, self.hm = ctx.f32(B, self.cr), ctx.f32(B, self.cr)
+        self.coefB, self.dmax = ctx.f32(B, Cn), ctx.f32(B, Cn)
+        self.red_part = ctx.f32(B * self.rows, 2, Cn)
+        self.ws = ctx.f32(B * (Cn + 2 * self.cr))
+        self.ones, self.zeros = ctx.const(1.0, Cn), ctx.const(0.0, Cn)
+        self.sink = GradSink(ctx, [mod.mlp[0].weight, mod.mlp[2].weight])
+        self.busy = False
+
+    def _desc(self):
+        d = InsarCam()
+        d.B, d.H, d.W, d.C, d.Cr, d.rows = self.B, self.H, self.W, self.C, self.cr, self.rows
+        d.psum, d.pmax, d.parg = ptr(self.psum), ptr(self.pmax), ptr(self.parg)
+        d.w1, d.w2 = ptr(self.mod.mlp[0].weight.detach()), ptr(self.mod.mlp[2].weight.detach())   # (Cr,C,1,1), (C,Cr,1,1)
+        d.avg, d.mx, d.arg = ptr(self.avg), ptr(self.mx), ptr(self.arg)
+        d.ha, d.hm, d.gate = ptr(self.ha), ptr(self.hm), ptr(self.gate)
+        d.coefB, d.dmax, d.ws = ptr(self.coefB), ptr(self.dmax), ptr(self.ws)
+        d.accumulate = 0
+        return d
+
+    def forward(self, x):
+        s = _lib.stream_ptr()
+        pack_input(x, self.x)
+        call("insar_cam_pool", self.x.ref, ptr(self.psum), ptr(self.pmax), ptr(self.parg), self.rpp, s)
+        d = self._desc()
+        call("insar_cam_excite", C.byref(d), s)
+        call("insar_bn_relu_apply", self.x.ref, ptr(self.ones), ptr(self.zeros), ptr(self.gate), self.out.ref, 0, s)
+        return unpack_output(self.out)
+
+    def backward(self, g):
+        s = _lib.stream_ptr()
+        self.sink.select()
+        pack_input(g, self.dout)
+        call("insar_bnrelu_bwd_reduce", self.dout.ref, self.x.ref, ptr(self.ones), ptr(self.zeros), ptr(self.red_part), 0, self.rpp, s)
+        w1, w2 = self.mod.mlp[0].weight, self.mod.mlp[2].weight
+        d = self._desc()
+        d.dw1, d.dw2 = ptr(self.sink.view(w1)), ptr(self.sink.view(w2))
+        call("insar_cam_bwd_coef", C.byref(d), ptr(self.red_part), self.rows, s)
+        call("insar_bnrelu_bwd_apply", self.dout.ref, self.x.ref, ptr(self.ones), ptr(self.zeros), ptr(self.zeros),
+             ptr(self.ones), ptr(self.gate), ptr(self.coefB), ptr(self.zeros), ptr(self.zeros), self.dx.ref, 0, s)
+        call("insar_cam_scatter_max", self.dx.ref, ptr(self.dmax), ptr(self.arg), s)
+        return unpack_output(self.dx), self.sink.view(w1), self.sink.view(w2)
+
+
+class ChannelAttentionModule(nn.Module):
+    """Channel attention of the DeepLabV3 variant (DeepLabV3-ChannelAttention.py:49-79): same constructor,
+    attribute names (`avg_pool`, `max_pool`, `mlp`, `sigmoid`) and state_dict (`mlp.0.weight`, `mlp.2.weight`)."""
+
+    def __init__(self, in_channels: int, reduction_ratio: int = 16):
+        super().__init__()
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.max_pool = nn.AdaptiveMaxPool2d(1)
+        self.mlp = nn.Sequential(
+            nn.Conv2d(in_channels, in_channels // reduction_ratio, 1, bias=False),
+            nn.ReLU(),
+            nn.Conv2d(in_channels // reduction_ratio, in_channels, 1, bias=False),
+        )
+        self.sigmoid = nn.Sigmoid()
+        self.compute_dtype: Optional[torch.dtype] = None
+        self._plans = _PlanCache()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _require_device(x, "ChannelAttentionModule")
+        b, c, h, w = x.shape
+        dt = _resolve_dtype(self)
+        plan = self._plans.get((b, c, h, w, dt, x.device), lambda: _CamPlan(self, b, c, h, w, dt, x.device))
+        return _SEFn.apply(plan, torch.is_grad_enabled(), x, self.mlp[0].weight, self.mlp[2].weight)
 
 
 # ------------------------------------------------------------------------------------------------

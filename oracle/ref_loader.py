@@ -54,3 +54,26 @@ def load_reference_unet_ca():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+def load_reference_deeplab_ca():
+    """Return the reference module object for DeepLabV3-ChannelAttention.py (config 5). Only its
+    ChannelAttentionModule (:49-79) is usable here: the DeepLab constructor needs torchvision and fetches
+    ImageNet weights and is never called. The import prints the device (:41-45)."""
+    _install_torchvision_stub()
+    if "torchvision.models" not in sys.modules:
+        def _unavailable(*_a, **_k):
+            raise NotImplementedError("torchvision is not installed; inert stub")
+        models = types.ModuleType("torchvision.models")
+        seg = types.ModuleType("torchvision.models.segmentation")
+        seg.deeplabv3_resnet50 = _unavailable
+        seg.deeplabv3_resnet101 = _unavailable
+        models.segmentation = seg
+        sys.modules["torchvision"].models = models
+        sys.modules["torchvision.models"] = models
+        sys.modules["torchvision.models.segmentation"] = seg
+    path = os.path.join(REFERENCE_ROOT, "DeepLabV3-ChannelAttention.py")
+    spec = importlib.util.spec_from_file_location("ref_deeplab_ca", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod

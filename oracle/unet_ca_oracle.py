@@ -95,6 +95,18 @@ def se_layer(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, name: str = ""
     return x * gate.view(b, c, 1, 1)                    # :72
 
 
+def cam_layer(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """ChannelAttentionModule.forward, DeepLabV3-ChannelAttention.py:66-79: a shared bias-free MLP of two 1x1
+    convolutions (:59-63; weights (C/r, C, 1, 1) and (C, C/r, 1, 1)) on the spatial mean and on the spatial
+    maximum, summed, sigmoid, times x."""
+    b, c = x.shape[0], x.shape[1]
+    w1m, w2m = w1.reshape(w1.shape[0], c), w2.reshape(c, w2.shape[1])
+    avg = x.mean(dim=(2, 3))                                  # AdaptiveAvgPool2d(1)   :68
+    mx = x.amax(dim=(2, 3))                                   # AdaptiveMaxPool2d(1)   :69
+    out = torch.relu(avg @ w1m.t()) @ w2m.t() + torch.relu(mx @ w1m.t()) @ w2m.t()    # :72
+    return x * torch.sigmoid(out).view(b, c, 1, 1)            # :75-78
+
+
 def _bn_relu(x, sd, prefix, training, eps, momentum):
     """BatchNorm2d (+ReLU), Unet-ChannalAttention.py:82-83,85-86. Updates running stats in `sd`
     (momentum 0.1, unbiased variance) when training, like nn.BatchNorm2d."""

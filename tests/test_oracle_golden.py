@@ -52,6 +52,24 @@ def test_se_layer(golden, tag, c, shape, salt):
     check_summary(g1, f"{tag}/step0/grad/fc.2.weight", w2.grad, TOL)
 
 
+@pytest.mark.parametrize("tag,c,shape", [("cam256", 256, (2, 256, 8, 8)), ("cam64_ties", 64, (3, 64, 12, 20))])
+def test_channel_attention_module(golden, tag, c, shape):
+    """G7: ChannelAttentionModule of the DeepLabV3 variant (config 5), incl. exact ties for the maximum."""
+    g7 = golden("g7_cam")
+    tmpl = OrderedDict([("mlp.0.weight", torch.zeros(c // 16, c, 1, 1)), ("mlp.2.weight", torch.zeros(c, c // 16, 1, 1))])
+    sd = _filled(tmpl)
+    w1 = sd["mlp.0.weight"].requires_grad_(True)
+    w2 = sd["mlp.2.weight"].requires_grad_(True)
+    x = torch.from_numpy(g7[f"{tag}/x"]) if f"{tag}/x" in g7.files else cf.make_input(shape, 0.4)
+    x = x.clone().requires_grad_(True)
+    out = orc.cam_layer(x, w1, w2)
+    out.backward(cf.make_grad(out.shape))
+    check_summary(g7, f"{tag}/step0/out", out, TOL)
+    check_summary(g7, f"{tag}/step0/dx", x.grad, TOL)
+    check_summary(g7, f"{tag}/step0/grad/mlp.0.weight", w1.grad, TOL)
+    check_summary(g7, f"{tag}/step0/grad/mlp.2.weight", w2.grad, TOL)
+
+
 def _dc_template(cin, cout, use_se):
     return OrderedDict((k[len("blk."):], torch.zeros(s, dtype=torch.int64 if k.endswith("tracked") else torch.float32))
                        for k, s in orc._double_conv_entries("blk", cin, cout, use_se))

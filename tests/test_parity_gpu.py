@@ -284,6 +284,37 @@ def test_se_layer_golden(dev, golden, tag, c, shape, salt):
     check_summary(g1, f"{tag}/step0/grad/fc.2.weight", mod.fc[2].weight.grad, 1e-4)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("tag,c,shape", [("cam256", 256, (2, 256, 8, 8)), ("cam64_ties", 64, (3, 64, 12, 20))])
+def test_channel_attention_module_golden(dev, golden, tag, c, shape, dtype):
+    """G7 (config 5's ChannelAttentionModule, vectors from the reference's class): forward, input gradient
+    (mean branch spread over the image, max branch routed to the FIRST maximum in scan order, tie cases
+    included) and both MLP weight gradients."""
+    import insar_unet_ca_amd as iu
+    g7 = golden("g7_cam")
+    mod = _filled(iu.ChannelAttentionModule(c, 16)).to(dev)
+    mod.compute_dtype = dtype
+    assert list(mod.state_dict().keys()) == ["mlp.0.weight", "mlp.2.weight"]
+    x0 = torch.from_numpy(g7[f"{tag}/x"]) if f"{tag}/x" in g7.files else cf.make_input(shape, 0.4)
+    x = x0.to(dev).requires_grad_(True)
+    out = mod(x)
+    out.backward(cf.make_grad(out.shape).to(dev))
+    if dtype == torch.float32:
+        check_summary(g7, f"{tag}/step0/out", out, 1e-5)
+        check_summary(g7, f"{tag}/step0/dx", x.grad, 1e-5)
+        check_summary(g7, f"{tag}/step0/grad/mlp.0.weight", mod.mlp[0].weight.grad, 1e-4)
+        check_summary(g7, f"{tag}/step0/grad/mlp.2.weight", mod.mlp[2].weight.grad, 1e-4)
+    else:                                   # bf16 storage of x, out, dout, dx; fp32 pooling / MLP
+        check_summary(g7, f"{tag}/step0/out", out, 1e-2)
+        if tag == "cam256":
+            check_summary(g7, f"{tag}/step0/dx", x.grad, 2e-2)
+        else:   # rounding x to bf16 merges near-maxima into ties: the max-branch gradient may land on another pixel
+            nrm = float(g7[f"{tag}/step0/dx/norm"])
+            assert abs(float(x.grad.double().norm()) - nrm) <= 0.05 * nrm
+        check_summary(g7, f"{tag}/step0/grad/mlp.0.weight", mod.mlp[0].weight.grad, 6e-2)
+        check_summary(g7, f"{tag}/step0/grad/mlp.2.weight", mod.mlp[2].weight.grad, 6e-2)
+
+
 def _relu_mask_disagreements(runner, oracle_masks):
     """Count pre-activations whose ReLU decision differs from the oracle's (values within rounding of 0)."""
     n = 0
