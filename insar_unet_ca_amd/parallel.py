@@ -27,7 +27,7 @@ class BucketReducer:
         self.backend = dist.get_backend(process_group)
 
     def reduce_slice(self, flat: torch.Tensor, begin: int, end: int) -> None:
-        if end <= begin or self.world == 1:
+        if end <= begin:
             return
         view = flat[begin:end]
         if self.backend == "nccl":

@@ -66,3 +66,51 @@ def test_data_parallel_two_ranks_one_gpu(tmp_path):
         assert torch.equal(r0["reduced"][k], r1["reduced"][k]), k
     # replicas stay identical after the optimizer step (same averaged gradients, same start)
     assert torch.equal(r0["w"], r1["w"]) and torch.equal(r0["w0"], r1["w0"])
+
+
+def _nccl_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd.data import make_batch
+    from insar_unet_ca_amd.parallel import DataParallel
+
+    torch.manual_seed(7)
+    net = iu.UNet(2, 2, True, compute_dtype=torch.bfloat16).to(dev).train()
+    x, y = make_batch(0, 2, 64)
+    x, y = x.to(dev), y.to(dev)
+    crit = iu.DiceCELoss(ignore_index=255)
+    crit(net(x), y).backward()
+    plain = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+    model = DataParallel(net, bucket_mb=4.0)          # RCCL broadcast of parameters and buffers
+    opt = iu.Adam(net.parameters(), lr=1e-4)
+    opt.zero_grad()
+    for _ in range(2):                                  # two steps: bucket bookkeeping resets between steps
+        opt.zero_grad()
+        loss = crit(model(x), y)
+        loss.backward()                                 # bucketed ReduceOp.AVG all-reduces from inside backward
+        if _ == 0:
+            same = all(torch.equal(plain[k], p.grad) for k, p in net.named_parameters())
+        opt.step()
+    torch.cuda.synchronize()
+    dist.barrier(device_ids=[0])
+    torch.save({"same": same, "loss": float(loss)}, os.path.join(out_dir, "nccl.pt"))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_over_rccl_single_rank(tmp_path):
+    """The RCCL code path itself (process-group init with device_id, parameter broadcast, asynchronous
+    ReduceOp.AVG all-reduces of the flat-gradient slices issued from inside backward with the side stream
+    joined first, work.wait() on the compute stream) on the one GPU a test box has: world size 1, where the
+    averaged gradient must equal the local one bit for bit. Multi-GPU RCCL runs are the driver's."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm device")
+    port = 29700 + (os.getpid() % 1000)
+    mp.spawn(_nccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(tmp_path / "nccl.pt")
+    assert r["same"] and r["loss"] == r["loss"]
