@@ -394,6 +394,10 @@ class ConvBN:
     # ---- forward: y = conv(x); BN statistics; scale/shift ---------------------------------------
     def forward_conv(self, training: bool) -> None:
         s = _lib.stream_ptr()
+        if training and self.M <= 1:
+            # nn.BatchNorm2d's own check (torch.nn.functional._verify_batch_size), same exception and text
+            raise ValueError("Expected more than 1 value per channel when training, got input size "
+                             f"torch.Size([{self.x.B}, {self.cout}, {self.x.H}, {self.x.W}])")
         if self.small:
             w = self.conv.weight.detach()
             call("insar_conv3x3_small_fwd", self.x.ref, ptr(w), self.y.ref, ptr(self.stats) if training else 0, s)

@@ -601,6 +601,51 @@ def test_unet_variants_against_oracle(dev, use_se, cin):
             assert int(b) == int(sd[k]) == 1
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,ncls,shape", [
+    (1, 2, (2, 1, 16, 16)),        # the smallest legal training input: a 1x1 bottleneck with two values per channel
+    (3, 3, (5, 3, 32, 16)),        # odd batch, non-square, three classes
+    (4, 8, (2, 4, 16, 48)),        # the widest first layer / class count the path takes
+    (2, 2, (1, 2, 80, 336)),       # rows longer than a tile; 336 = the widest row the 64->64 kernel's window takes
+])
+def test_unet_edge_geometries(dev, cin, ncls, shape, dtype):
+    """Edge geometries of the whole path (forward, loss, backward, Adam) against the oracle: fp32 within the
+    north_star tolerance; bf16 finite, same arg-max on >= 90 % of the pixels and a finite update."""
+    import insar_unet_ca_amd as iu
+    net = iu.UNet(cin, ncls, True, compute_dtype=dtype)
+    net.load_state_dict(cf.fill_state_dict_random(net.state_dict(), seed=41))
+    sd = OrderedDict((k, v.detach().clone()) for k, v in net.state_dict().items())
+    net = net.to(dev).train()
+    x = cf.make_input_random(shape, seed=42)
+    rng = np.random.Generator(np.random.PCG64(43))
+    tgt = torch.from_numpy(rng.integers(0, ncls, size=(shape[0], shape[2], shape[3])).astype(np.int64))
+    opt = iu.Adam(net.parameters(), lr=1e-4)
+    logits = net(x.to(dev))
+    loss = iu.CrossEntropyLoss(ignore_index=255)(logits, tgt.to(dev))
+    loss.backward()
+    opt.step()
+    ref = orc.unet_forward(sd, x, use_se=True, training=True)
+    assert logits.shape == ref.shape
+    if dtype == torch.float32:
+        assert max_rel(logits, ref) <= FWD_TOL
+        assert abs(float(loss.detach()) - float(orc.cross_entropy(ref, tgt))) <= 1e-4
+    else:
+        assert (logits.argmax(1).cpu() == ref.argmax(1)).float().mean().item() >= 0.9
+    assert all(torch.isfinite(p).all() and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_single_value_per_channel_is_refused_like_batchnorm(dev):
+    """A 1x1x16x16 training input leaves one value per channel at the bottleneck: nn.BatchNorm2d raises
+    ValueError there (and so does the reference); eval mode works."""
+    import insar_unet_ca_amd as iu
+    net = iu.UNet(1, 2, True).to(dev)
+    x = torch.zeros(1, 1, 16, 16, device=dev)
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
+        net.train()(x)
+    with torch.no_grad():
+        assert net.eval()(x).shape == (1, 2, 16, 16)
+
+
 # ------------------------------------------------------------------------------------------------
 # bf16 compute path
 # ------------------------------------------------------------------------------------------------
