@@ -142,6 +142,9 @@ typedef struct InsarWgrad {
   int32_t offx[12];       /* per-tap pixel offset added to tabx entries */
   int32_t offdy[12];      /* per-tap pixel offset added to tabdy entries */
 } InsarWgrad;
+/* tile extent the kernel uses along a channel dimension of C channels: 64 | 128 | 256 (256 only when both
+ * Cin and Cout allow it, otherwise capped at 128); needed by callers that size the split-K factor. */
+int insar_wgrad_tile(int32_t C, int32_t dtype);
 int insar_wgrad(const InsarWgrad* d, void* stream);
 /* grad = sum_split part[...] re-laid out to the torch parameter layout.
  * layout 0: Conv2d (Co,Ci,kh,kw): grad[(co*Ci+ci)*ntaps + tap]

@@ -13,6 +13,8 @@
 //    16 channels -> per-lane 4 consecutive pixels of one channel), rows XOR-swizzled on the DMA
 //    source so the transposed reads are bank-conflict-free; fp32 uses ds_read_b32 +
 //    v_mfma_f32_16x16x4_f32;
+//  * tiles: (Cin, Cout) = 64/128 x 64/128 with 4 waves and two work-groups per CU, or 256 x 256 with 8 waves
+//    (wave tile 128 x 64) where both channel counts allow it: half the DMA pieces per MFMA (734 vs ~600 TF/s);
 //  * each work-group owns one (split, tap, ci-tile, co-tile) and writes its fp32 partial tile with
 //    16-byte stores; insar_wgrad_reduce folds the splits and re-lays the result out to the torch
 //    parameter layout. Bitwise reproducible.
@@ -22,7 +24,6 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-#define WG_THREADS 256
 #define WG_BKP 64  // pixels per K step
 
 struct WgradArgs {
@@ -42,22 +43,27 @@ __device__ __forceinline__ int wg_swz(int row) {
   else return ((row >> 1) & 3) << 1;
 }
 
-template <typename T, int TM, int TN>
+// NW waves = 2 (along TM) x NW/2 (along TN). Operand rows wider than 256 bytes are kept as SUB side-by-side
+// sub-tiles of 256-byte rows ([sub][64 pixels][256 B]) so that one swizzle serves every width.
+template <typename T, int TM, int TN, int NW>
 struct WgradCfg {
   static constexpr int ES = sizeof(T);
-  static constexpr int RBX = TM * ES, RBY = TN * ES;         // tile row bytes (128 or 256)
-  static constexpr int X_STAGE = WG_BKP * RBX, Y_STAGE = WG_BKP * RBY;
+  static constexpr int THREADS = NW * 64;
+  static constexpr int SUBX = (TM * ES > 256) ? TM * ES / 256 : 1, SUBY = (TN * ES > 256) ? TN * ES / 256 : 1;
+  static constexpr int RBX = TM * ES / SUBX, RBY = TN * ES / SUBY;   // sub-tile row bytes (128 or 256)
+  static constexpr int X_STAGE = WG_BKP * TM * ES, Y_STAGE = WG_BKP * TN * ES;
   static constexpr int STAGE = X_STAGE + Y_STAGE;
   static constexpr int LDS_BYTES = 2 * STAGE + 128;          // + tap offsets
   static constexpr int CPRX = RBX / 16, CPRY = RBY / 16;
-  static constexpr int NX = WG_BKP * CPRX / WG_THREADS;      // DMA chunks per thread per step
-  static constexpr int NY = WG_BKP * CPRY / WG_THREADS;
-  static constexpr int MTW = TM / 32, NTW = TN / 32;         // 16x16 tiles per wave (wave = TM/2 x TN/2)
+  static constexpr int NX = X_STAGE / 16 / THREADS;          // DMA chunks per thread per step
+  static constexpr int NY = Y_STAGE / 16 / THREADS;
+  static constexpr int MTW = TM / 32, NTW = TN / (NW / 2) / 16;   // 16x16 tiles per wave
 };
 
-template <typename T, int TM, int TN>
-__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(WgradArgs a) {
-  using Cfg = WgradCfg<T, TM, TN>;
+template <typename T, int TM, int TN, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad_kernel(WgradArgs a) {
+  using Cfg = WgradCfg<T, TM, TN, NW>;
+  constexpr int WG_THREADS = Cfg::THREADS;
   constexpr int ES = Cfg::ES;
   constexpr int MTW = Cfg::MTW, NTW = Cfg::NTW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -86,35 +92,40 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(WgradArgs a) {
   long long ks1 = ks0 + a.steps_per_split;
   if (ks1 > a.ksteps) ks1 = a.ksteps;
 
-  // staging geometry: chunk q = i*256 + tid -> row q / CPR, lane-linear position q % CPR
-  const int xrow = tid / Cfg::CPRX, xpos = tid % Cfg::CPRX;   // + i * (256 / CPRX) rows
-  const int yrow = tid / Cfg::CPRY, ypos = tid % Cfg::CPRY;
-  constexpr int XRS = WG_THREADS / Cfg::CPRX, YRS = WG_THREADS / Cfg::CPRY;
+  // staging geometry: chunk q = i*THREADS + tid -> sub-tile q / (64*CPR), row (q / CPR) % 64, position q % CPR
   const long long xcol = ((long long)a.cx_off + mi * TM) * ES;
   const long long ycol = ((long long)a.cdy_off + ni * TN) * ES;
+  auto xgeo = [&](int i, int& sub, int& row, int& pos) {
+    const int q = i * WG_THREADS + tid;
+    sub = q / (WG_BKP * Cfg::CPRX); row = (q / Cfg::CPRX) % WG_BKP; pos = q % Cfg::CPRX;
+  };
+  auto ygeo = [&](int i, int& sub, int& row, int& pos) {
+    const int q = i * WG_THREADS + tid;
+    sub = q / (WG_BKP * Cfg::CPRY); row = (q / Cfg::CPRY) % WG_BKP; pos = q % Cfg::CPRY;
+  };
 
   int32_t px[Cfg::NX], py[Cfg::NY];
   auto load_tabs = [&](long long ks) {
 #pragma unroll
-    for (int i = 0; i < Cfg::NX; ++i) px[i] = a.tabx[ks * WG_BKP + xrow + i * XRS];
+    for (int i = 0; i < Cfg::NX; ++i) { int sub, row, pos; xgeo(i, sub, row, pos); px[i] = a.tabx[ks * WG_BKP + row]; }
 #pragma unroll
-    for (int i = 0; i < Cfg::NY; ++i) py[i] = a.tabdy[ks * WG_BKP + yrow + i * YRS];
+    for (int i = 0; i < Cfg::NY; ++i) { int sub, row, pos; ygeo(i, sub, row, pos); py[i] = a.tabdy[ks * WG_BKP + row]; }
   };
   const uint32_t lds0 = lds_offset_of(smem);
   auto stage = [&](int buf) {
     const uint32_t lx = lds0 + buf * Cfg::STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < Cfg::NX; ++i) {
-      const int row = xrow + i * XRS;
-      const int sc = xpos ^ wg_swz<Cfg::RBX>(row);
-      lds_dma16_untracked(a.x + ((long long)px[i] + offx) * a.Cx * ES + xcol + sc * 16, lx + i * 4096);
+      int sub, row, pos; xgeo(i, sub, row, pos);
+      const int sc = pos ^ wg_swz<Cfg::RBX>(row);
+      lds_dma16_untracked(a.x + ((long long)px[i] + offx) * a.Cx * ES + xcol + sub * Cfg::RBX + sc * 16, lx + i * (WG_THREADS * 16));
     }
     const uint32_t ly = lx + Cfg::X_STAGE;
 #pragma unroll
     for (int i = 0; i < Cfg::NY; ++i) {
-      const int row = yrow + i * YRS;
-      const int sc = ypos ^ wg_swz<Cfg::RBY>(row);
-      lds_dma16_untracked(a.dy + ((long long)py[i] + offdy) * a.Cdy * ES + ycol + sc * 16, ly + i * 4096);
+      int sub, row, pos; ygeo(i, sub, row, pos);
+      const int sc = pos ^ wg_swz<Cfg::RBY>(row);
+      lds_dma16_untracked(a.dy + ((long long)py[i] + offdy) * a.Cdy * ES + ycol + sub * Cfg::RBY + sc * 16, ly + i * (WG_THREADS * 16));
     }
   };
 
@@ -153,17 +164,19 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(WgradArgs a) {
             const int row = s * 32 + kq * 8 + sel * 4 + (r16 >> 2);
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) {
-              const int colb = (wm * (TM / 2) + mt * 16 + (r16 & 3) * 4) * 2;      // byte column
+              const int colw = (wm * (TM / 2) + mt * 16 + (r16 & 3) * 4) * 2;      // byte column in the tile row
+              const int sub = colw / Cfg::RBX, colb = colw % Cfg::RBX;
               const int pc = (colb >> 4) ^ wg_swz<Cfg::RBX>(row);
-              const char* p = sX + row * Cfg::RBX + pc * 16 + (colb & 15);
+              const char* p = sX + sub * (WG_BKP * Cfg::RBX) + row * Cfg::RBX + pc * 16 + (colb & 15);
               s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
               xf[mt][4 * h + 0] = v[0]; xf[mt][4 * h + 1] = v[1]; xf[mt][4 * h + 2] = v[2]; xf[mt][4 * h + 3] = v[3];
             }
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
-              const int colb = (wn * (TN / 2) + nt * 16 + (r16 & 3) * 4) * 2;
+              const int colw = (wn * (NTW * 16) + nt * 16 + (r16 & 3) * 4) * 2;
+              const int sub = colw / Cfg::RBY, colb = colw % Cfg::RBY;
               const int pc = (colb >> 4) ^ wg_swz<Cfg::RBY>(row);
-              const char* p = sY + row * Cfg::RBY + pc * 16 + (colb & 15);
+              const char* p = sY + sub * (WG_BKP * Cfg::RBY) + row * Cfg::RBY + pc * 16 + (colb & 15);
               s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
               yf[nt][4 * h + 0] = v[0]; yf[nt][4 * h + 1] = v[1]; yf[nt][4 * h + 2] = v[2]; yf[nt][4 * h + 3] = v[3];
             }
@@ -181,15 +194,17 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(WgradArgs a) {
           float xf[MTW], yf[NTW];
 #pragma unroll
           for (int mt = 0; mt < MTW; ++mt) {
-            const int colb = (wm * (TM / 2) + mt * 16 + r16) * 4;
+            const int colw = (wm * (TM / 2) + mt * 16 + r16) * 4;
+            const int sub = colw / Cfg::RBX, colb = colw % Cfg::RBX;
             const int pc = (colb >> 4) ^ wg_swz<Cfg::RBX>(row);
-            xf[mt] = *(const float*)(sX + row * Cfg::RBX + pc * 16 + (colb & 15));
+            xf[mt] = *(const float*)(sX + sub * (WG_BKP * Cfg::RBX) + row * Cfg::RBX + pc * 16 + (colb & 15));
           }
 #pragma unroll
           for (int nt = 0; nt < NTW; ++nt) {
-            const int colb = (wn * (TN / 2) + nt * 16 + r16) * 4;
+            const int colw = (wn * (NTW * 16) + nt * 16 + r16) * 4;
+            const int sub = colw / Cfg::RBY, colb = colw % Cfg::RBY;
             const int pc = (colb >> 4) ^ wg_swz<Cfg::RBY>(row);
-            yf[nt] = *(const float*)(sY + row * Cfg::RBY + pc * 16 + (colb & 15));
+            yf[nt] = *(const float*)(sY + sub * (WG_BKP * Cfg::RBY) + row * Cfg::RBY + pc * 16 + (colb & 15));
           }
 #pragma unroll
           for (int mt = 0; mt < MTW; ++mt)
@@ -209,26 +224,33 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
       const int ci = mi * TM + wm * (TM / 2) + mt * 16 + kq * 4;
-      const int co = ni * TN + wn * (TN / 2) + nt * 16 + r16;
+      const int co = ni * TN + wn * (NTW * 16) + nt * 16 + r16;
       *(f32x4_t*)(out + (long long)co * a.Cin + ci) = acc[mt][nt];
     }
 }
 
-template <typename T, int TM, int TN>
+template <typename T, int TM, int TN, int NW>
 static int launch_wgrad(WgradArgs& a, hipStream_t s) {
-  using Cfg = WgradCfg<T, TM, TN>;
+  using Cfg = WgradCfg<T, TM, TN, NW>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<T, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<T, TM, TN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
   a.mtc = a.Cin / TM; a.ntc = a.Cout / TN;
   const long long grid = (long long)a.nsplit * a.ntaps * a.mtc * a.ntc;
   if (grid > 0x7fffffffLL) INSAR_FAIL(INSAR_E_SHAPE, "insar_wgrad: grid too large");
-  hipLaunchKernelGGL((wgrad_kernel<T, TM, TN>), dim3((unsigned)grid), dim3(WG_THREADS), Cfg::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((wgrad_kernel<T, TM, TN, NW>), dim3((unsigned)grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, a);
   INSAR_CHECK_LAUNCH("insar_wgrad");
   return INSAR_OK;
+}
+
+// Tile extent along a channel dimension of C channels (the Cin x Cout tile of a launch is tile(Cin) x tile(Cout),
+// except that 256 is used only when BOTH dimensions allow it: 8 waves, 128 KB of LDS, half the DMA pieces per MFMA).
+extern "C" int insar_wgrad_tile(int32_t C, int32_t dtype) {
+  if (dtype != INSAR_BF16) return 64;
+  return (C % 256) == 0 ? 256 : ((C % 128) == 0 ? 128 : 64);
 }
 
 extern "C" int insar_wgrad(const InsarWgrad* d, void* stream) {
@@ -250,14 +272,16 @@ extern "C" int insar_wgrad(const InsarWgrad* d, void* stream) {
   a.Cdy = d->dy.C; a.cdy_off = d->dy.c_off; a.Cout = Cout;
   for (int t = 0; t < 12; ++t) { a.offx[t] = t < d->ntaps ? d->offx[t] : 0; a.offdy[t] = t < d->ntaps ? d->offdy[t] : 0; }
   hipStream_t s = (hipStream_t)stream;
+  const int tm = insar_wgrad_tile(Cin, d->x.dtype), tn = insar_wgrad_tile(Cout, d->x.dtype);
   if (d->x.dtype == INSAR_BF16) {
-    const bool m128 = (Cin % 128) == 0, n128 = (Cout % 128) == 0;
-    if (m128 && n128) return launch_wgrad<bf16_t, 128, 128>(a, s);
-    if (m128) return launch_wgrad<bf16_t, 128, 64>(a, s);
-    if (n128) return launch_wgrad<bf16_t, 64, 128>(a, s);
-    return launch_wgrad<bf16_t, 64, 64>(a, s);
+    if (tm == 256 && tn == 256) return launch_wgrad<bf16_t, 256, 256, 8>(a, s);
+    const bool m128 = tm >= 128, n128 = tn >= 128;
+    if (m128 && n128) return launch_wgrad<bf16_t, 128, 128, 4>(a, s);
+    if (m128) return launch_wgrad<bf16_t, 128, 64, 4>(a, s);
+    if (n128) return launch_wgrad<bf16_t, 64, 128, 4>(a, s);
+    return launch_wgrad<bf16_t, 64, 64, 4>(a, s);
   }
-  return launch_wgrad<float, 64, 64>(a, s);
+  return launch_wgrad<float, 64, 64, 4>(a, s);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -280,11 +280,18 @@ def _conv3x3_c64(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[tor
     call("insar_conv3x3_c64", x.ref, y.ref, ptr(w), flip, ptr(stats), _lib.stream_ptr())
 
 
+def _wgrad_tiles(cin: int, cout: int, code: int):
+    """(Cin, Cout) tile of the weight-gradient kernel (csrc/wgrad.hip: insar_wgrad_tile)."""
+    tm, tn = call("insar_wgrad_tile", cin, code), call("insar_wgrad_tile", cout, code)
+    if tm == 256 and tn == 256:
+        return 256, 256
+    return min(tm, 128), min(tn, 128)
+
+
 def _launch_wgrad(d: InsarWgrad, M: int, cin: int, cout: int, ntaps: int, code: int) -> None:
     if PROFILER is not None:
-        tm = 128 if (code == _lib.BF16 and cin % 128 == 0) else 64
-        tn = 128 if (code == _lib.BF16 and cout % 128 == 0) else 64
-        tag = "wgrad_kernel<%s, %d, %d>" % ("float" if code == _lib.F32 else "bf16_t", tm, tn)
+        tm, tn = _wgrad_tiles(cin, cout, code)
+        tag = "wgrad_kernel<%s, %d, %d, %d>" % ("float" if code == _lib.F32 else "bf16_t", tm, tn, 8 if tm == 256 else 4)
         PROFILER.run(tag, 2.0 * M * cin * cout * ntaps, lambda: call("insar_wgrad", C.byref(d), _lib.stream_ptr()))
         return
     call("insar_wgrad", C.byref(d), _lib.stream_ptr())
@@ -481,8 +488,7 @@ def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
     tabx = ctx.pixel_table(B, H, W, 1, H, W, W + 3)      # taps move on x: tail = first interior pixel
     tabdy = ctx.pixel_table(B, H, W, 1, H, W, 0)         # tail = zero halo pixel
     mpad = tabx.numel()
-    tm = 128 if (ctx.code == _lib.BF16 and cin % 128 == 0) else 64
-    tn = 128 if (ctx.code == _lib.BF16 and cout % 128 == 0) else 64
+    tm, tn = _wgrad_tiles(cin, cout, ctx.code)
     tiles = 9 * (cin // tm) * (cout // tn)
     nsplit = _wgrad_nsplit(tiles, mpad // WG_BKP, 9 * cout * cin, tm, tn, ctx.esize)
     part = ctx.wgrad_part(nsplit * 9 * cout * cin)
@@ -588,8 +594,7 @@ class UpPlan:
         tabx = ctx.pixel_table(B, h, w, 1, h, w, 0)
         tabdy = ctx.pixel_table(B, h, w, 2, dout.H, dout.W, 0)
         mpad = tabx.numel()
-        tm = 128 if (ctx.code == _lib.BF16 and self.cin % 128 == 0) else 64
-        tn = 128 if (ctx.code == _lib.BF16 and self.cout % 128 == 0) else 64
+        tm, tn = _wgrad_tiles(self.cin, self.cout, ctx.code)
         tiles = 4 * (self.cin // tm) * (self.cout // tn)
         nsplit = _wgrad_nsplit(tiles, mpad // WG_BKP, 4 * self.cout * self.cin, tm, tn, ctx.esize)
         with ctx.side_stream():
