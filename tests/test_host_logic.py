@@ -76,6 +76,8 @@ def mocked_abi(monkeypatch):
             return (a[0] + 127) // 128
         if name == "insar_igemm_tile_rows":
             return 128
+        if name == "insar_wgrad_tile":
+            return 64
         if name in ("insar_conv3x3_flat_ok", "insar_conv3x3_flat_num_mtiles"):
             return 0
         if name == "insar_conv3x3_small_wgrad_blocks":
