@@ -502,7 +502,7 @@ def test_unet_fp32_gradients_given_equal_relu_decisions(dev, fixture, shape):
     """The tight gradient statement. ReLU is the only discontinuity of the network: where a pre-activation
     sits within forward rounding noise of 0 (|z| < ~1e-5; a few dozen of the 3.5 M elements) two fp32
     implementations may decide differently, and each such flip moves every upstream gradient by ~2e-3
-    (tools/debug_fwd_noise.py: all of this path's flips have |z| < 8e-6). The same holds for the ReLU inside
+    (tests/tools/debug_fwd_noise.py: all of this path's flips have |z| < 8e-6). The same holds for the ReLU inside
     the SE bottleneck and for near-ties in a max-pool window. So (1) the decisions of the HIP path may differ
     from a float64 oracle's only at |z| < 1e-4 and in at most 40 places, and (2) under the HIP path's OWN
     decisions (oracle ReLU replaced by y * mask, pooling by a gather at the given indices) every parameter
@@ -972,7 +972,7 @@ def test_train_loop_over_the_voc_reader(dev, tmp_path):
 def test_miou_parity_task(dev, dtype):
     """north_star's mIoU clause at the resolution the task allows. tests/golden/g8b_miou_parity.json holds the
     oracle's validation-mIoU curves on a 64x64 synthetic task (256 train / 256 held-out tiles, 12 epochs, same
-    tiles, order and initial weights as here, tools/miou_parity.py) for the plain run and for two runs with
+    tiles, order and initial weights as here, tests/tools/miou_parity.py) for the plain run and for two runs with
     1e-6 relative noise on the training inputs: their last-4-epoch means are 0.549 / 0.581 / 0.569, i.e. the
     reference algorithm itself is only reproducible to ~3 pt on this metric (Adam + ReLU/BN chaos, 3-8 %
     positive pixels). The HIP path must land inside that band widened by 4 pt (round 1 on MI355X: fp32 0.580,

@@ -2,7 +2,7 @@
 G3r fixture. Prints rel-L2 of y1 (raw conv1 output, bias removed), z1, y2, block output."""
 import os, sys, torch, torch.nn.functional as F
 from collections import OrderedDict
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 torch.set_num_threads(16)
 import insar_unet_ca_amd as iu
 from oracle import closed_form as cf, unet_ca_oracle as orc

@@ -1,6 +1,6 @@
 """Bring-up harness: run every kernel family against torch/oracle references on the GPU and
 print per-stage max-rel errors. Not a pytest (it keeps going after a failure so one GPU
-session yields the whole picture). Usage: python tools/gpu_check.py [--only name,...]"""
+session yields the whole picture). Usage: python tests/tools/gpu_check.py [--only name,...]"""
 from __future__ import annotations
 
 import argparse
@@ -13,7 +13,7 @@ from collections import OrderedDict
 import torch
 import torch.nn.functional as F
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import insar_unet_ca_amd as iu  # noqa: E402

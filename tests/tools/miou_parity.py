@@ -9,7 +9,7 @@ import argparse, json, os, sys, time
 from collections import OrderedDict
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 from insar_unet_ca_amd.data import make_batch
 from oracle import closed_form as cf, unet_ca_oracle as orc
 
