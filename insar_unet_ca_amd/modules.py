@@ -9,6 +9,7 @@ fallback: calling `forward` with a non-ROCm tensor raises.
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 from typing import Dict, Optional, Tuple
 
@@ -57,11 +58,25 @@ class _Lease:
 
 
 class _PlanCache:
+    """Plans (preallocated buffers + launch sequence) per input geometry. A plan for config 2 holds ~6 GB, so
+    the cache keeps at most `MAX_KEYS` geometries and drops the least recently used idle ones beyond that
+    (a loader with a ragged last batch needs two; variable tile sizes must not grow memory without bound)."""
+
+    MAX_KEYS = 4
+
     def __init__(self):
-        self.plans: Dict[tuple, list] = {}
+        self.plans: "collections.OrderedDict[tuple, list]" = collections.OrderedDict()
 
     def get(self, key, factory):
-        lst = self.plans.setdefault(key, [])
+        lst = self.plans.get(key)
+        if lst is None:
+            lst = self.plans[key] = []
+            for old in list(self.plans.keys()):
+                if len(self.plans) <= self.MAX_KEYS:
+                    break
+                if old != key and not any(p.busy for p in self.plans[old]):
+                    del self.plans[old]
+        self.plans.move_to_end(key)
         for p in lst:
             if not p.busy:
                 return p

@@ -165,3 +165,20 @@ def test_metrics_arithmetic_matches_reference_fixture(golden, case):
     tp, fp, fn = orc.confusion_counts(torch.from_numpy(g6[f"{case}/logits"]), torch.from_numpy(g6[f"{case}/mask"]), 2)
     m = metrics_from_counts(tp, fp, fn)
     np.testing.assert_allclose([m[k] for k in ("acc", "miou", "mpa", "mf1")], g6[f"{case}/expect"], atol=1e-12)
+
+
+def test_plan_cache_is_bounded():
+    """At most MAX_KEYS geometries stay cached; idle least-recently-used ones go first, busy ones never."""
+    cache = modules._PlanCache()
+
+    class P:
+        def __init__(self):
+            self.busy = False
+
+    made = [cache.get(("k", i), P) for i in range(3)]
+    made[0].busy = True                                   # e.g. between a forward and its backward
+    for i in range(3, 8):
+        cache.get(("k", i), P)
+    assert len(cache.plans) <= cache.MAX_KEYS + 1         # the busy geometry may exceed the cap by one
+    assert ("k", 0) in cache.plans and ("k", 7) in cache.plans and ("k", 1) not in cache.plans
+    assert cache.get(("k", 7), P) is cache.plans[("k", 7)][0]      # idle plan reused, not rebuilt
