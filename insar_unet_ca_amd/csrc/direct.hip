@@ -138,8 +138,8 @@ extern "C" int insar_conv3x3_small_fwd(const InsarAct* x, const float* w, const 
 // own the same channel chunk (wave shuffles, then LDS across waves) and writes ONE partial row:
 // part[block][Co*Ci*9] in torch (Co,Ci,3,3) order. insar_colsum folds the blocks.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void conv3x3_small_wgrad_kernel(ActView x, ActView dy, float* __restrict__ part) {
+template <typename T, int CIB>    // CIB input channels per pass over dy (2 for even Cin: dy is read once for Cin = 2)
+__global__ void __launch_bounds__(DR_THREADS) conv3x3_small_wgrad_kernel(ActView x, ActView dy, float* __restrict__ part) {
   constexpr int CH = Chunk<T>::N;
   extern __shared__ float sm[];                     // [4 waves][cpp][9][CH]
   const int Ci = x.c_len, Co = dy.c_len;
@@ -148,12 +148,14 @@ __global__ void conv3x3_small_wgrad_kernel(ActView x, ActView dy, float* __restr
   const int total = dy.W * cpp;
   const int cc = threadIdx.x % cpp;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int ci = 0; ci < Ci; ++ci) {
-    float acc[9][CH];
+  for (int ci0 = 0; ci0 < Ci; ci0 += CIB) {
+    float acc[CIB][9][CH];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int c = 0; c < CIB; ++c)
 #pragma unroll
-      for (int j = 0; j < CH; ++j) acc[t][j] = 0.f;
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < CH; ++j) acc[c][t][j] = 0.f;
     for (int r = blockIdx.x; r < rows; r += gridDim.x) {
       const int n = r / dy.H, h = r - n * dy.H;
       for (int e = threadIdx.x; e < total; e += blockDim.x) {
@@ -162,45 +164,51 @@ __global__ void conv3x3_small_wgrad_kernel(ActView x, ActView dy, float* __restr
         Chunk<T>::unpack(*(const uint4*)(dy.base + (dy.elem_offset(n, h, w) + (int64_t)cc * CH) * (int64_t)sizeof(T)), g);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-          const float xv = load_elem<T>(x.base + (x.elem_offset(n, h + t / 3 - 1, w + t % 3 - 1) + ci) * (int64_t)sizeof(T));
+          float xv[CIB];
+          load_pixel<T, CIB>(x.base + (x.elem_offset(n, h + t / 3 - 1, w + t % 3 - 1) + ci0) * (int64_t)sizeof(T), xv);
 #pragma unroll
-          for (int j = 0; j < CH; ++j) acc[t][j] = fmaf(xv, g[j], acc[t][j]);
+          for (int c = 0; c < CIB; ++c)
+#pragma unroll
+            for (int j = 0; j < CH; ++j) acc[c][t][j] = fmaf(xv[c], g[j], acc[c][t][j]);
         }
       }
     }
-    // lanes with equal (lane % cpp) own the same channels
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-      for (int j = 0; j < CH; ++j) {
-        float v = acc[t][j];
-        for (int o = cpp; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-        acc[t][j] = v;
-      }
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-      for (int j = 0; j < CH; ++j) LDS_PIN(acc[t][j]);
-    if (lane < cpp) {
+    for (int c = 0; c < CIB; ++c) {
+      // lanes with equal (lane % cpp) own the same channels
 #pragma unroll
       for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int j = 0; j < CH; ++j) sm[((wave * cpp + lane) * 9 + t) * CH + j] = acc[t][j];
-    }
-    LDS_DRAIN();
+        for (int j = 0; j < CH; ++j) {
+          float v = acc[c][t][j];
+          for (int o = cpp; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+          acc[c][t][j] = v;
+        }
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+      for (int t = 0; t < 9; ++t)
 #pragma unroll
-      for (int j = 0; j < CH; ++j) LDS_KEEP(acc[t][j]);
-    __syncthreads();
-    for (int o = threadIdx.x; o < Co * 9; o += blockDim.x) {
-      const int co = o / 9, t = o - co * 9;
-      const int occ = co / CH, j = co - occ * CH;
-      float s = 0.f;
-      for (int w4 = 0; w4 < (int)(blockDim.x >> 6); ++w4) s += sm[((w4 * cpp + occ) * 9 + t) * CH + j];
-      part[(int64_t)blockIdx.x * (Co * Ci * 9) + ((int64_t)co * Ci + ci) * 9 + t] = s;
+        for (int j = 0; j < CH; ++j) LDS_PIN(acc[c][t][j]);
+      if (lane < cpp) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int j = 0; j < CH; ++j) sm[((wave * cpp + lane) * 9 + t) * CH + j] = acc[c][t][j];
+      }
+      LDS_DRAIN();
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < CH; ++j) LDS_KEEP(acc[c][t][j]);
+      __syncthreads();
+      for (int o = threadIdx.x; o < Co * 9; o += blockDim.x) {
+        const int co = o / 9, t = o - co * 9;
+        const int occ = co / CH, j = co - occ * CH;
+        float s = 0.f;
+        for (int w4 = 0; w4 < (int)(blockDim.x >> 6); ++w4) s += sm[((w4 * cpp + occ) * 9 + t) * CH + j];
+        part[(int64_t)blockIdx.x * (Co * Ci * 9) + ((int64_t)co * Ci + ci0 + c) * 9 + t] = s;
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
 }
 
@@ -218,8 +226,14 @@ extern "C" int insar_conv3x3_small_wgrad(const InsarAct* x, const InsarAct* dy, 
   size_t lds = (size_t)4 * cpp * 9 * ch * sizeof(float);
   int grid = insar_conv3x3_small_wgrad_blocks(dy->B, dy->H);
   hipStream_t s = (hipStream_t)stream;
-  if (dy->dtype == INSAR_BF16) hipLaunchKernelGGL(conv3x3_small_wgrad_kernel<bf16_t>, dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), make_view(*dy), part);
-  else hipLaunchKernelGGL(conv3x3_small_wgrad_kernel<float>, dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), make_view(*dy), part);
+  const bool pair = (x->c_len % 2) == 0 && (x->C % 2) == 0 && (x->c_off % 2) == 0;      // aligned 2-channel loads
+  if (dy->dtype == INSAR_BF16) {
+    if (pair) hipLaunchKernelGGL((conv3x3_small_wgrad_kernel<bf16_t, 2>), dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), make_view(*dy), part);
+    else hipLaunchKernelGGL((conv3x3_small_wgrad_kernel<bf16_t, 1>), dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), make_view(*dy), part);
+  } else {
+    if (pair) hipLaunchKernelGGL((conv3x3_small_wgrad_kernel<float, 2>), dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), make_view(*dy), part);
+    else hipLaunchKernelGGL((conv3x3_small_wgrad_kernel<float, 1>), dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), make_view(*dy), part);
+  }
   INSAR_CHECK_LAUNCH("insar_conv3x3_small_wgrad");
   return INSAR_OK;
 }
