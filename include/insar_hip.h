@@ -164,6 +164,8 @@ int insar_pixel_table(int32_t* tab, int64_t Mpad, int32_t B, int32_t H, int32_t 
                       int32_t Hb, int32_t Wb, int32_t tail, void* stream);
 
 /* ---- first layer: direct 3x3 conv for tiny Cin (inc.double_conv.0, Cin<=4; :81 with :464) ---- */
+/* rows of the statistics slab insar_conv3x3_small_fwd writes for this (x, y): stats[rows][2][Cout] */
+int insar_conv3x3_small_fwd_rows(const InsarAct* x, const InsarAct* y);
 int insar_conv3x3_small_fwd(const InsarAct* x, const float* w /*torch (Co,Ci,3,3) fp32*/,
                             const InsarAct* y, float* stats /*[B*H][2][Co]*/, void* stream);
 /* part: [insar_conv3x3_small_wgrad_blocks(B,H)][Co*Ci*9] partial rows (torch (Co,Ci,3,3) order). */

@@ -99,6 +99,7 @@ _SIGNATURES = {
     "insar_wgrad_fold": [_P, _P, _L, _I, _I, _P],
     "insar_pixel_table": [_P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
     "insar_conv3x3_small_fwd": [_AP, _P, _AP, _P, _P],
+    "insar_conv3x3_small_fwd_rows": [_AP, _AP],
     "insar_conv3x3_small_wgrad_blocks": [_I, _I],
     "insar_conv3x3_small_wgrad": [_AP, _AP, _P, _P],
     "insar_colsum": [_P, _P, _I, _L, _I, _I, _P, _L, _P],
@@ -160,7 +161,7 @@ def load():
     return lib
 
 
-_COUNT_ONLY = {"insar_igemm_num_mtiles", "insar_igemm_tile_rows", "insar_igemm_tile_cols", "insar_wgrad_tile", "insar_conv3x3_flat_ok", "insar_conv3x3_flat_num_mtiles", "insar_conv3x3_c64_ok", "insar_conv3x3_c64_rows", "insar_conv3x3_small_wgrad_blocks", "insar_conv1x1_out_bwd_blocks",
+_COUNT_ONLY = {"insar_igemm_num_mtiles", "insar_igemm_tile_rows", "insar_igemm_tile_cols", "insar_wgrad_tile", "insar_conv3x3_flat_ok", "insar_conv3x3_flat_num_mtiles", "insar_conv3x3_c64_ok", "insar_conv3x3_c64_rows", "insar_conv3x3_small_wgrad_blocks", "insar_conv3x3_small_fwd_rows", "insar_conv1x1_out_bwd_blocks",
                "insar_ce_blocks"}
 
 

@@ -48,13 +48,19 @@ conv3x3_small_fwd_kernel(ActView x, const float* __restrict__ wt, ActView y, flo
   const int rows = y.B * y.H;
   const int total = y.W * cpp;
   const int cc = threadIdx.x % cpp;                 // host guarantees blockDim % cpp == 0
-  float wr[9][CI][CH];                              // torch layout (Co, Ci, 3, 3)
+  // weights and accumulators as float2 pairs: the multiply-adds become v_pk_fma_f32 (two lanes of work per
+  // instruction; this kernel is VALU-bound: 9*CI*CH FMAs per 16 bytes stored)
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 wr[9][CI][CH / 2];                             // torch layout (Co, Ci, 3, 3)
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
     for (int ci = 0; ci < CI; ++ci)
 #pragma unroll
-      for (int j = 0; j < CH; ++j) wr[tap][ci][j] = wt[((int64_t)(cc * CH + j) * CI + ci) * 9 + tap];
+      for (int j = 0; j < CH / 2; ++j) {
+        wr[tap][ci][j].x = wt[((int64_t)(cc * CH + 2 * j) * CI + ci) * 9 + tap];
+        wr[tap][ci][j].y = wt[((int64_t)(cc * CH + 2 * j + 1) * CI + ci) * 9 + tap];
+      }
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const int n = r / y.H, h = r - n * y.H;
     float s1[CH], s2[CH];
@@ -62,19 +68,24 @@ conv3x3_small_fwd_kernel(ActView x, const float* __restrict__ wt, ActView y, flo
     for (int j = 0; j < CH; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
       const int w = e / cpp;
-      float acc[CH];
+      f2 acc2[CH / 2];
 #pragma unroll
-      for (int j = 0; j < CH; ++j) acc[j] = 0.f;
+      for (int j = 0; j < CH / 2; ++j) acc2[j] = (f2){0.f, 0.f};
       const char* p0 = x.base + x.elem_offset(n, h - 1, w - 1) * (int64_t)sizeof(T);
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         float xv[CI];
         load_pixel<T, CI>(p0 + ((int64_t)(tap / 3) * (x.W + 2) + (tap % 3)) * x.C * (int64_t)sizeof(T), xv);
 #pragma unroll
-        for (int ci = 0; ci < CI; ++ci)
+        for (int ci = 0; ci < CI; ++ci) {
+          const f2 xx = (f2){xv[ci], xv[ci]};
 #pragma unroll
-          for (int j = 0; j < CH; ++j) acc[j] = fmaf(xv[ci], wr[tap][ci][j], acc[j]);
+          for (int j = 0; j < CH / 2; ++j) acc2[j] = __builtin_elementwise_fma(xx, wr[tap][ci][j], acc2[j]);
+        }
       }
+      float acc[CH];
+#pragma unroll
+      for (int j = 0; j < CH / 2; ++j) { acc[2 * j] = acc2[j].x; acc[2 * j + 1] = acc2[j].y; }
       const uint4 packed = Chunk<T>::pack(acc);
       float f[CH];
       Chunk<T>::unpack(packed, f);                  // statistics of the stored (rounded) values
@@ -98,6 +109,128 @@ conv3x3_small_fwd_kernel(ActView x, const float* __restrict__ wt, ActView y, flo
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 first-layer forward on the matrix cores: K = 9*CI <= 32 fits ONE 16x16x32 MFMA step.
+// A wave takes 16 consecutive pixels of an image row; lane (pixel r16, k group kq) gathers its 8 patch
+// values k = 8*kq .. 8*kq+7 (k = tap*CI + ci; k >= 9*CI is zero) straight from global memory (L1 serves the
+// overlap between neighbouring pixels), the weights of the four 16-channel output tiles stay in 16 VGPRs
+// as MFMA A fragments, and every lane ends up with 4 consecutive channels of its pixel per tile: 8-byte
+// stores. ~60 VGPRs instead of 208 for the VALU version, whose two waves per SIMD could not hide the
+// load -> FMA -> store latency (98 us for a 134 MB write). Same per-image-row statistics slab.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) short d_bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float d_f32x4_t;
+
+template <int CI>
+__global__ void __launch_bounds__(DR_THREADS) conv3x3_small_fwd_mfma_kernel(ActView x, const float* __restrict__ wt, ActView y,
+                                                                           float* __restrict__ part) {
+  constexpr int KV = 9 * CI;                        // valid k
+  __shared__ float red[DR_THREADS / 64][2][64];     // per-wave channel sums
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int Co = y.c_len;                           // 64
+  // A fragments: weights[cout = nt*16 + r16][k = 8*kq + i], torch layout (Co, CI, 3, 3) fp32 -> bf16
+  d_bf16x8_t wf[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = 8 * kq + i;
+      float v = 0.f;
+      if (k < KV) v = wt[((int64_t)(nt * 16 + r16) * CI + (k % CI)) * 9 + (k / CI)];
+      wf[nt][i] = (short)f32_to_bf16(v);
+    }
+  const int rows = y.B * y.H;
+  const int groups = (y.W + 15) / 16;
+  // BatchNorm partial sums of the stored values: carried in registers over all rows of this work-group,
+  // written once: the slab has gridDim.x rows (insar_conv3x3_small_fwd_rows)
+  float s1[4][4], s2[4][4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s1[nt][j] = 0.f; s2[nt][j] = 0.f; }
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int n = r / y.H, h = r - n * y.H;
+    for (int g = wave; g < groups; g += nw) {
+      const int w = g * 16 + r16;
+      const bool ok = w < y.W;
+      const int wc = ok ? w : y.W - 1;              // clamp: lanes past the row end compute a duplicate, never store it
+      d_bf16x8_t xf;
+      const char* p0 = x.base + x.elem_offset(n, h - 1, wc - 1) * (int64_t)sizeof(bf16_t);
+      if constexpr (CI == 2) {                      // both channels of a tap in one 4-byte load
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int tap = 4 * kq + i;
+          uint32_t v = 0;
+          if (tap < 9) v = *(const uint32_t*)(p0 + ((int64_t)(tap / 3) * (x.W + 2) + (tap % 3)) * x.C * 2);
+          xf[2 * i] = (short)(v & 0xffffu); xf[2 * i + 1] = (short)(v >> 16);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int k = 8 * kq + i;
+          short v = 0;
+          if (k < KV) {
+            const int tap = k / CI, ci = k - tap * CI;
+            v = *(const short*)(p0 + (((int64_t)(tap / 3) * (x.W + 2) + (tap % 3)) * x.C + ci) * 2);
+          }
+          xf[i] = v;
+        }
+      }
+      char* yp = y.base + (y.elem_offset(n, h, wc) + kq * 4) * (int64_t)2;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        d_f32x4_t acc = (d_f32x4_t){0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf, acc, 0, 0, 0);
+        const uint16_t b0 = f32_to_bf16(acc[0]), b1 = f32_to_bf16(acc[1]), b2 = f32_to_bf16(acc[2]), b3 = f32_to_bf16(acc[3]);
+        if (ok) {
+          uint2 v;
+          v.x = (uint32_t)b0 | ((uint32_t)b1 << 16);
+          v.y = (uint32_t)b2 | ((uint32_t)b3 << 16);
+          *(uint2*)(yp + nt * 32) = v;
+          const float f0 = bf16_to_f32(b0), f1 = bf16_to_f32(b1), f2 = bf16_to_f32(b2), f3 = bf16_to_f32(b3);
+          s1[nt][0] += f0; s2[nt][0] = fmaf(f0, f0, s2[nt][0]);
+          s1[nt][1] += f1; s2[nt][1] = fmaf(f1, f1, s2[nt][1]);
+          s1[nt][2] += f2; s2[nt][2] = fmaf(f2, f2, s2[nt][2]);
+          s1[nt][3] += f3; s2[nt][3] = fmaf(f3, f3, s2[nt][3]);
+        }
+      }
+    }
+  }
+  if (part) {
+    // lanes with equal kq hold the same channels: fold over r16, then over the waves
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int sh = 1; sh < 16; sh <<= 1) { s1[nt][j] += __shfl_xor(s1[nt][j], sh, 64); s2[nt][j] += __shfl_xor(s2[nt][j], sh, 64); }
+        LDS_PIN(s1[nt][j]); LDS_PIN(s2[nt][j]);
+      }
+    if (r16 == 0) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          red[wave][0][nt * 16 + kq * 4 + j] = s1[nt][j];
+          red[wave][1][nt * 16 + kq * 4 + j] = s2[nt][j];
+        }
+    }
+    LDS_DRAIN();
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { LDS_KEEP(s1[nt][j]); LDS_KEEP(s2[nt][j]); }
+    __syncthreads();
+    if (threadIdx.x < 2 * Co) {
+      const int q = threadIdx.x / Co, c = threadIdx.x - q * Co;
+      float v = 0.f;
+      for (int wv = 0; wv < nw; ++wv) v += red[wv][q][c];
+      part[((int64_t)blockIdx.x * 2 + q) * Co + c] = v;
+    }
+  }
+}
+
 static int check_small(const InsarAct* x, const InsarAct* y, const char* who) {
   if (!x || !y || !x->ptr || !y->ptr) INSAR_FAIL(INSAR_E_ARG, "%s: null pointer", who);
   if (x->dtype != y->dtype) INSAR_FAIL(INSAR_E_DTYPE, "%s: dtype differ", who);
@@ -110,6 +243,18 @@ static int check_small(const InsarAct* x, const InsarAct* y, const char* who) {
   return insar_check_act(y, who, "y");
 }
 
+static inline bool small_fwd_uses_mfma(const InsarAct* x, const InsarAct* y) {
+  return y->dtype == INSAR_BF16 && y->c_len == 64 && x->c_len <= 3;
+}
+// rows of the BatchNorm partial-sum slab insar_conv3x3_small_fwd writes: one per image row for the VALU
+// version, one per work-group for the matrix-core version
+extern "C" int insar_conv3x3_small_fwd_rows(const InsarAct* x, const InsarAct* y) {
+  if (!x || !y) return 0;
+  const int64_t r = (int64_t)y->B * y->H;
+  if (small_fwd_uses_mfma(x, y)) return (int)(r > 1024 ? 1024 : r);
+  return (int)r;
+}
+
 extern "C" int insar_conv3x3_small_fwd(const InsarAct* x, const float* w, const InsarAct* y, float* stats, void* stream) {
   int rc;
   if ((rc = check_small(x, y, "insar_conv3x3_small_fwd"))) return rc;
@@ -120,7 +265,15 @@ extern "C" int insar_conv3x3_small_fwd(const InsarAct* x, const float* w, const 
   hipStream_t s = (hipStream_t)stream;
   const ActView xv = make_view(*x), yv = make_view(*y);
 #define SMALL_FWD(T, CI) hipLaunchKernelGGL((conv3x3_small_fwd_kernel<T, CI>), dim3(grid), dim3(DR_THREADS), 0, s, xv, w, yv, stats)
-  if (y->dtype == INSAR_BF16) {
+  if (small_fwd_uses_mfma(x, y)) {
+    // matrix-core version (K = 9*Cin <= 32); its statistics slab has one row per work-group
+    grid = insar_conv3x3_small_fwd_rows(x, y);
+    switch (x->c_len) {
+      case 1: hipLaunchKernelGGL((conv3x3_small_fwd_mfma_kernel<1>), dim3(grid), dim3(DR_THREADS), 0, s, xv, w, yv, stats); break;
+      case 2: hipLaunchKernelGGL((conv3x3_small_fwd_mfma_kernel<2>), dim3(grid), dim3(DR_THREADS), 0, s, xv, w, yv, stats); break;
+      default: hipLaunchKernelGGL((conv3x3_small_fwd_mfma_kernel<3>), dim3(grid), dim3(DR_THREADS), 0, s, xv, w, yv, stats); break;
+    }
+  } else if (y->dtype == INSAR_BF16) {
     switch (x->c_len) { case 1: SMALL_FWD(bf16_t, 1); break; case 2: SMALL_FWD(bf16_t, 2); break;
                         case 3: SMALL_FWD(bf16_t, 3); break; default: SMALL_FWD(bf16_t, 4); break; }
   } else {

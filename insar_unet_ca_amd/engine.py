@@ -376,7 +376,7 @@ class ConvBN:
         self.flat_fwd = (not self.small) and not self.c64 and bool(call("insar_conv3x3_flat_ok", x.ref, self.cout))
         self.flat_bwd = (not self.small) and not self.c64 and bool(call("insar_conv3x3_flat_ok", x.ref, self.cin))
         if self.small:
-            self.stat_rows = B * H
+            self.stat_rows = call("insar_conv3x3_small_fwd_rows", x.ref, self.y.ref)
         elif self.c64:
             self.stat_rows = call("insar_conv3x3_c64_rows", x.ref)
         elif self.flat_fwd:

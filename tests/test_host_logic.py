@@ -80,6 +80,8 @@ def mocked_abi(monkeypatch):
             return 64
         if name in ("insar_conv3x3_flat_ok", "insar_conv3x3_flat_num_mtiles"):
             return 0
+        if name == "insar_conv3x3_small_fwd_rows":
+            return 64
         if name == "insar_conv3x3_small_wgrad_blocks":
             return min(a[0] * a[1], 512)
         if name == "insar_conv1x1_out_bwd_blocks":

@@ -193,6 +193,30 @@ def test_conv3x3_c64_against_float64(dev, shape):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,shape", [(1, (2, 1, 16, 16)), (2, (3, 2, 24, 40)), (3, (1, 3, 16, 20)), (4, (2, 4, 16, 32))])
+def test_first_layer_conv_against_float64(dev, dtype, cin, shape):
+    """The direct first-layer conv (Cin <= 4; bf16 with Cin <= 3 runs on the matrix cores with bf16 weights,
+    rows not a multiple of 16 pixels included) and its statistics slab, against float64 on its own operands."""
+    from insar_unet_ca_amd import _lib, engine
+    from insar_unet_ca_amd._lib import call, ptr
+    b, _, h, w = shape
+    xa = _act_from(cf.make_input(shape, 0.3), dtype, dev)
+    ya = engine.Act.alloc(b, h, w, 64, dtype, dev)
+    wt = cf.fill_tensor("weight", (64, cin, 3, 3), 5).to(dev)
+    rows = call("insar_conv3x3_small_fwd_rows", xa.ref, ya.ref)
+    stats = torch.full((rows, 2, 64), float("nan"), device=dev)
+    call("insar_conv3x3_small_fwd", xa.ref, ptr(wt), ya.ref, ptr(stats), _lib.stream_ptr())
+    mfma = dtype == torch.bfloat16 and cin <= 3
+    wref = (wt.to(torch.bfloat16) if mfma else wt).double().cpu()
+    ref = F.conv2d(xa.nchw().cpu().double(), wref, padding=1)
+    assert max_rel(ya.nchw(), ref) <= (KERNEL_TOL if dtype == torch.float32 else 6e-3)
+    assert _halo_abs(ya) == 0.0
+    got = ya.nchw().double().cpu()
+    assert max_rel(stats.sum(0)[0], got.sum((0, 2, 3))) <= 1e-4
+    assert max_rel(stats.sum(0)[1], (got ** 2).sum((0, 2, 3))) <= 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_weight_relayout_single_and_batched(dev, dtype):
     """GEMM-operand forms of Conv2d / ConvTranspose2d weights: the per-weight kernel and the one-launch
     paired kernel (both forms from one read) give exactly the permutations of the fp32 master."""
