@@ -662,18 +662,24 @@ __global__ void __launch_bounds__(COEF_THREADS) se_excite_kernel(InsarSeFwd d) {
   float* hid = sm + d.C;     // [Cr]
   float* pool = hid + d.Cr;  // [2C]
   float* scratch = pool + 2 * d.C;   // [blockDim]
+  // grid (B, S): the S work-groups of an image all fold its squeeze rows and run the first Linear (cheap,
+  // L2-served), and share the rows of the second Linear: this kernel is latency-bound, and with one
+  // work-group per image only B of the 256 CUs had anything to do (56 us at C = 1024).
   const int n = blockIdx.x;
+  const bool writer = blockIdx.y == 0;
   const float inv_hw = 1.f / ((float)d.H * (float)d.W);
   // fold this image's squeeze rows: part[(n*rows + r)][2][C]
   block_colsum(d.part + (int64_t)n * d.rows * 2 * d.C, d.rows, 2 * d.C, pool, scratch);
   for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
     const float q0 = pool[c];
     const float q1 = pool[d.C + c];
-    d.pooled[((int64_t)n * 2 + 0) * d.C + c] = q0;
-    d.pooled[((int64_t)n * 2 + 1) * d.C + c] = q1;
     const float m = (d.scale[c] * q1 + d.shift[c] * q0) * inv_hw;
     sq[c] = m;
-    d.sq[(int64_t)n * d.C + c] = m;
+    if (writer) {
+      d.pooled[((int64_t)n * 2 + 0) * d.C + c] = q0;
+      d.pooled[((int64_t)n * 2 + 1) * d.C + c] = q1;
+      d.sq[(int64_t)n * d.C + c] = m;
+    }
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
@@ -685,26 +691,28 @@ __global__ void __launch_bounds__(COEF_THREADS) se_excite_kernel(InsarSeFwd d) {
     if (lane == 0) {
       const float hv = fmaxf(acc, 0.f);
       hid[j] = hv;
-      d.hid[(int64_t)n * d.Cr + j] = hv;
+      if (writer) d.hid[(int64_t)n * d.Cr + j] = hv;
     }
   }
   __syncthreads();
   // gate[c] = sigmoid(sum_j w2[c][j] * hid[j]): one wave per row of w2, lanes over j (coalesced)
-  // (8 rows per trip so that their loads are in flight together: this block is latency-bound)
-  for (int c0 = wave; c0 < d.C; c0 += 8 * nw) {
+  // (8 rows per trip so that their loads are in flight together); this work-group's slice of the rows
+  const int per = (d.C + gridDim.y - 1) / gridDim.y;
+  const int cbeg = blockIdx.y * per, cend = min(d.C, cbeg + per);
+  for (int c0 = cbeg + wave; c0 < cend; c0 += 8 * nw) {
     float acc[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int c = c0 + u * nw;
       acc[u] = 0.f;
-      if (c < d.C)
+      if (c < cend)
         for (int j = lane; j < d.Cr; j += 64) acc[u] = fmaf(d.w2[(int64_t)c * d.Cr + j], hid[j], acc[u]);
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int c = c0 + u * nw;
       const float t = wave_sum(acc[u]);
-      if (lane == 0 && c < d.C) d.gate[(int64_t)n * d.C + c] = 1.f / (1.f + __expf(-t));
+      if (lane == 0 && c < cend) d.gate[(int64_t)n * d.C + c] = 1.f / (1.f + __expf(-t));
     }
   }
 }
@@ -714,7 +722,9 @@ extern "C" int insar_se_excite(const InsarSeFwd* d, void* stream) {
     INSAR_FAIL(INSAR_E_ARG, "insar_se_excite: null pointer");
   if (d->B < 1 || d->C < 1 || d->Cr < 1 || d->C > 4096 || d->rows < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_se_excite: bad shape");
   size_t lds = (size_t)(3 * d->C + d->Cr + COEF_THREADS) * sizeof(float);
-  hipLaunchKernelGGL(se_excite_kernel, dim3(d->B), dim3(COEF_THREADS), lds, (hipStream_t)stream, *d);
+  int split = d->C / 128;                          // work-groups per image: 128 rows of the second Linear each
+  split = split < 1 ? 1 : (split > 8 ? 8 : split);
+  hipLaunchKernelGGL(se_excite_kernel, dim3(d->B, split), dim3(COEF_THREADS), lds, (hipStream_t)stream, *d);
   INSAR_CHECK_LAUNCH("insar_se_excite");
   return INSAR_OK;
 }
