@@ -283,19 +283,24 @@ __global__ __launch_bounds__(2 * BM, 2) void igemm_kernel(IgemmArgs a) {
   }
 }
 
-// Tile selection: the 256-row / 8-wave / 3-slab-ring variant needs enough tiles to fill 256 CUs;
-// small-M layers (the 16x16 and 32x32 levels) keep the 128-row / 2-slab variant at 2 blocks per CU.
+// Tile selection: the 256-row / 8-wave / 3-slab-ring variant needs enough tiles to fill 256 CUs: 256 x 128
+// tiles where that gives >= 256 of them, else 256 x 64 tiles if THOSE fill the chip (the 16x16 level with
+// 1024 output channels: 1 % of the step faster than 128 x 64 tiles); the remaining small grids keep the
+// 128-row / 2-slab variant at 2 blocks per CU.
 static inline int igemm_bm_for(long long M, int N) {
   const int bn = (N % 128) == 0 ? 128 : 64;
   const long long tiles256 = ((M + 255) / 256) * (N / bn);
-  return tiles256 >= 256 ? 256 : 128;
+  if (tiles256 >= 256) return 256;
+  // 256 x 64 tiles when they (and only they) fill the chip: still the 8-wave / 3-slab kernel
+  if (((M + 255) / 256) * (N / 64) >= 256) return 256;
+  return 128;
 }
 // Output-channel tile: 128 wide where N allows, except on grids so small that 128x128 tiles would leave one
 // 4-wave work-group per CU (the 16x16 level): 128x64 tiles double the work-groups (two per CU, two waves
 // per SIMD to hide each other's LDS and barrier latency).
 static inline int igemm_bn_for(long long M, int N) {
   if (N % 128) return 64;
-  if (igemm_bm_for(M, N) == 256) return 128;
+  if (igemm_bm_for(M, N) == 256) return ((M + 255) / 256) * (N / 128) >= 256 ? 128 : 64;
   const long long tiles = ((M + 127) / 128) * (N / 128);
   return tiles <= 256 ? 64 : 128;
 }
