@@ -79,6 +79,7 @@ def _halo_abs(a):
     (64, 64, (3, 64, 120, 200)),     # 72000 pixels: 256-row tiles (3-slab ring), ragged last tile
     (64, 128, (4, 64, 128, 128)),    # 65536 pixels: 256-row tiles, N = 128
     (256, 512, (4, 256, 32, 32)),    # 256x256 weight-gradient tiles (8 waves) with split-K, two Cout tiles
+    (64, 1024, (4, 64, 32, 32)),     # 4096 pixels x 1024 channels: the 256x64 tile choice
 ])
 def test_igemm_family_against_float64(dev, dtype, cin, cout, shape):
     from insar_unet_ca_amd import engine
