@@ -89,8 +89,11 @@ class DataParallel(torch.nn.Module):
         ends, closes = plan.stage_ends, plan.bucket_closes(self.min_elems)
         if self._stage in closes:
             end = ends[self._stage]
-            plan.ctx.join_side()        # the bucket's weight gradients were computed on the side stream
-            self.reducer.reduce_slice(plan.sink.flat(), self._begin, end)
+            # The bucket's weight gradients were computed on the side stream, its BN / SE gradients on the main
+            # stream. Issuing the all-reduce from the side stream (which first waits for the main stream's
+            # position) orders the collective after both WITHOUT stalling the main stream's dgrad chain.
+            with plan.ctx.side_stream():
+                self.reducer.reduce_slice(plan.sink.flat(), self._begin, end)
             self._begin = end
         self._stage += 1
 
