@@ -113,8 +113,8 @@ conv3x3_small_fwd_kernel(ActView x, const float* __restrict__ wt, ActView y, flo
 // bf16 first-layer forward on the matrix cores: K = 9*CI <= 32 fits ONE 16x16x32 MFMA step.
 // A wave takes 16 consecutive pixels of an image row; lane (pixel r16, k group kq) gathers its 8 patch
 // values k = 8*kq .. 8*kq+7 (k = tap*CI + ci; k >= 9*CI is zero) straight from global memory (L1 serves the
-// overlap between neighbouring pixels), the weights of the four 16-channel output tiles stay in 16 VGPRs
-// as MFMA A fragments, and every lane ends up with 4 consecutive channels of its pixel per tile: 8-byte
+// overlap between neighbouring pixels), the weights of the four 16-channel output tiles stay in 32 VGPRs
+// as MFMA A fragments (bf16 head + remainder), and every lane ends up with 4 consecutive channels of its pixel per tile: 8-byte
 // stores. ~60 VGPRs instead of 208 for the VALU version, whose two waves per SIMD could not hide the
 // load -> FMA -> store latency (98 us for a 134 MB write). Same per-image-row statistics slab.
 // ---------------------------------------------------------------------------------------------
@@ -130,7 +130,9 @@ __global__ void __launch_bounds__(DR_THREADS) conv3x3_small_fwd_mfma_kernel(ActV
   const int r16 = lane & 15, kq = lane >> 4;
   const int Co = y.c_len;                           // 64
   // A fragments: weights[cout = nt*16 + r16][k = 8*kq + i], torch layout (Co, CI, 3, 3) fp32 -> bf16
-  d_bf16x8_t wf[4];
+  // The fp32 master weight goes in as a bf16 head + bf16 remainder (two MFMAs per tile: ~16 mantissa bits,
+  // as the VALU version's fp32 weights gave; the kernel is bound by its 134 MB of stores, not by the MFMAs).
+  d_bf16x8_t wf[4], wl[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -138,7 +140,9 @@ __global__ void __launch_bounds__(DR_THREADS) conv3x3_small_fwd_mfma_kernel(ActV
       const int k = 8 * kq + i;
       float v = 0.f;
       if (k < KV) v = wt[((int64_t)(nt * 16 + r16) * CI + (k % CI)) * 9 + (k / CI)];
-      wf[nt][i] = (short)f32_to_bf16(v);
+      const uint16_t hi = f32_to_bf16(v);
+      wf[nt][i] = (short)hi;
+      wl[nt][i] = (short)f32_to_bf16(v - bf16_to_f32(hi));
     }
   const int rows = y.B * y.H;
   const int groups = (y.W + 15) / 16;
@@ -181,6 +185,7 @@ __global__ void __launch_bounds__(DR_THREADS) conv3x3_small_fwd_mfma_kernel(ActV
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         d_f32x4_t acc = (d_f32x4_t){0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[nt], xf, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf, acc, 0, 0, 0);
         const uint16_t b0 = f32_to_bf16(acc[0]), b1 = f32_to_bf16(acc[1]), b2 = f32_to_bf16(acc[2]), b3 = f32_to_bf16(acc[3]);
         if (ok) {
