@@ -176,6 +176,7 @@ def main() -> int:
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "final_loss": round(final_loss, 5),
             "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 3),
+            "hbm_allocated_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
             "frac_of_mfma_roofline": round(per_gpu * FLOP_PER_TILE_256 * (args.size / 256) ** 2 / (PEAK_BF16_TFLOPS * 1e12), 4),
             "frac_of_hbm_roofline": round(per_gpu * BYTES_PER_TILE_BF16_B16 * (args.size / 256) ** 2 / (PEAK_HBM_GBS * 1e9), 4),
         }
