@@ -95,38 +95,44 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad_kernel(Wgrad
   // staging geometry: chunk q = i*THREADS + tid -> sub-tile q / (64*CPR), row (q / CPR) % 64, position q % CPR
   const long long xcol = ((long long)a.cx_off + mi * TM) * ES;
   const long long ycol = ((long long)a.cdy_off + ni * TN) * ES;
-  auto xgeo = [&](int i, int& sub, int& row, int& pos) {
+  // per-thread constants of its DMA chunks (hoisted: they do not depend on the K step)
+  int xrow_i[Cfg::NX], yrow_i[Cfg::NY];
+  int xoff_i[Cfg::NX], yoff_i[Cfg::NY];                       // byte offset inside the pixel's channel run
+#pragma unroll
+  for (int i = 0; i < Cfg::NX; ++i) {
     const int q = i * WG_THREADS + tid;
-    sub = q / (WG_BKP * Cfg::CPRX); row = (q / Cfg::CPRX) % WG_BKP; pos = q % Cfg::CPRX;
-  };
-  auto ygeo = [&](int i, int& sub, int& row, int& pos) {
+    const int sub = q / (WG_BKP * Cfg::CPRX), row = (q / Cfg::CPRX) % WG_BKP, pos = q % Cfg::CPRX;
+    xrow_i[i] = row;
+    xoff_i[i] = sub * Cfg::RBX + (pos ^ wg_swz<Cfg::RBX>(row)) * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < Cfg::NY; ++i) {
     const int q = i * WG_THREADS + tid;
-    sub = q / (WG_BKP * Cfg::CPRY); row = (q / Cfg::CPRY) % WG_BKP; pos = q % Cfg::CPRY;
-  };
+    const int sub = q / (WG_BKP * Cfg::CPRY), row = (q / Cfg::CPRY) % WG_BKP, pos = q % Cfg::CPRY;
+    yrow_i[i] = row;
+    yoff_i[i] = sub * Cfg::RBY + (pos ^ wg_swz<Cfg::RBY>(row)) * 16;
+  }
+  const char* xbase = a.x + offx * a.Cx * ES + xcol;
+  const char* ybase = a.dy + offdy * a.Cdy * ES + ycol;
+  const long long xpitch = (long long)a.Cx * ES, ypitch = (long long)a.Cdy * ES;
 
   int32_t px[Cfg::NX], py[Cfg::NY];
   auto load_tabs = [&](long long ks) {
 #pragma unroll
-    for (int i = 0; i < Cfg::NX; ++i) { int sub, row, pos; xgeo(i, sub, row, pos); px[i] = a.tabx[ks * WG_BKP + row]; }
+    for (int i = 0; i < Cfg::NX; ++i) px[i] = a.tabx[ks * WG_BKP + xrow_i[i]];
 #pragma unroll
-    for (int i = 0; i < Cfg::NY; ++i) { int sub, row, pos; ygeo(i, sub, row, pos); py[i] = a.tabdy[ks * WG_BKP + row]; }
+    for (int i = 0; i < Cfg::NY; ++i) py[i] = a.tabdy[ks * WG_BKP + yrow_i[i]];
   };
   const uint32_t lds0 = lds_offset_of(smem);
   auto stage = [&](int buf) {
     const uint32_t lx = lds0 + buf * Cfg::STAGE + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < Cfg::NX; ++i) {
-      int sub, row, pos; xgeo(i, sub, row, pos);
-      const int sc = pos ^ wg_swz<Cfg::RBX>(row);
-      lds_dma16_untracked(a.x + ((long long)px[i] + offx) * a.Cx * ES + xcol + sub * Cfg::RBX + sc * 16, lx + i * (WG_THREADS * 16));
-    }
+    for (int i = 0; i < Cfg::NX; ++i)
+      lds_dma16_untracked(xbase + (long long)px[i] * xpitch + xoff_i[i], lx + i * (WG_THREADS * 16));
     const uint32_t ly = lx + Cfg::X_STAGE;
 #pragma unroll
-    for (int i = 0; i < Cfg::NY; ++i) {
-      int sub, row, pos; ygeo(i, sub, row, pos);
-      const int sc = pos ^ wg_swz<Cfg::RBY>(row);
-      lds_dma16_untracked(a.dy + ((long long)py[i] + offdy) * a.Cdy * ES + ycol + sub * Cfg::RBY + sc * 16, ly + i * (WG_THREADS * 16));
-    }
+    for (int i = 0; i < Cfg::NY; ++i)
+      lds_dma16_untracked(ybase + (long long)py[i] * ypitch + yoff_i[i], ly + i * (WG_THREADS * 16));
   };
 
   f32x4_t acc[MTW][NTW];
@@ -165,7 +171,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad_kernel(Wgrad
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) {
               const int colw = (wm * (TM / 2) + mt * 16 + (r16 & 3) * 4) * 2;      // byte column in the tile row
-              const int sub = colw / Cfg::RBX, colb = colw % Cfg::RBX;
+              int sub = 0, colb = colw;
+              if constexpr (Cfg::SUBX > 1) { sub = colw / Cfg::RBX; colb = colw % Cfg::RBX; }
               const int pc = (colb >> 4) ^ wg_swz<Cfg::RBX>(row);
               const char* p = sX + sub * (WG_BKP * Cfg::RBX) + row * Cfg::RBX + pc * 16 + (colb & 15);
               s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
@@ -174,7 +181,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad_kernel(Wgrad
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
               const int colw = (wn * (NTW * 16) + nt * 16 + (r16 & 3) * 4) * 2;
-              const int sub = colw / Cfg::RBY, colb = colw % Cfg::RBY;
+              int sub = 0, colb = colw;
+              if constexpr (Cfg::SUBY > 1) { sub = colw / Cfg::RBY; colb = colw % Cfg::RBY; }
               const int pc = (colb >> 4) ^ wg_swz<Cfg::RBY>(row);
               const char* p = sY + sub * (WG_BKP * Cfg::RBY) + row * Cfg::RBY + pc * 16 + (colb & 15);
               s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
