@@ -522,6 +522,8 @@ _BLOCK_NAMES = ["inc", "down1.1", "down2.1", "down3.1", "down4.1"], ["conv1", "c
     ((21, 22, 23, 0.0), (2, 2, 64, 64)),
     ((31, 32, 33, 0.02), (3, 2, 48, 80)),         # ragged
     ("closed-form", (1, 2, 256, 256)),            # the G3 b1_256_train inputs (smooth, many near-zero z)
+    ((7, 11, 13, 0.05, "bf16"), (2, 2, 64, 64)),  # the bf16 compute path: same statement at bf16 resolution
+    ((31, 32, 33, 0.02, "bf16"), (3, 2, 48, 80)),
 ])
 def test_unet_fp32_gradients_given_equal_relu_decisions(dev, fixture, shape):
     """The tight gradient statement. ReLU is the only discontinuity of the network: where a pre-activation
@@ -533,7 +535,8 @@ def test_unet_fp32_gradients_given_equal_relu_decisions(dev, fixture, shape):
     decisions (oracle ReLU replaced by y * mask, pooling by a gather at the given indices) every parameter
     gradient matches the float64 oracle to 2e-4 rel-L2 (measured 1e-5 ... 3e-5)."""
     import insar_unet_ca_amd as iu
-    net = iu.UNet(2, 2, True)
+    bf16 = fixture != "closed-form" and len(fixture) > 4
+    net = iu.UNet(2, 2, True, compute_dtype=torch.bfloat16 if bf16 else None)
     hw = (shape[0], shape[2], shape[3])
     if fixture == "closed-form":
         net.load_state_dict(cf.fill_state_dict(net.state_dict()))
@@ -598,6 +601,15 @@ def test_unet_fp32_gradients_given_equal_relu_decisions(dev, fixture, shape):
     errs.sort(reverse=True)
     print("   worst gradient rel-L2:", ", ".join(f"{k} {e:.2e}" for e, k in errs[:6]))
     worst, name = errs[0]
+    if bf16:
+        # bf16 storage (8 bits of mantissa) moves tens of thousands of decisions (activations within 4e-3 of
+        # zero), which is why the comparison is made under the path's own decisions; what remains is bf16
+        # rounding of activations, gradients and GEMM operands through ~40 layers against exact float64
+        # arithmetic: measured 5-6.5e-2 for every conv / BN / convT tensor, up to 0.2 for the first SE Linear
+        # (sums of nearly cancelling per-channel terms).
+        for e, k in errs:
+            assert e <= (0.35 if k.endswith("fc.0.weight") else 0.1), f"bf16: gradient rel-L2 {e:.3e} at {k}"
+        return
     smooth = fixture == "closed-form"      # degenerate (near-constant) channels: invstd up to 316 amplifies the noise
     assert flips <= (2000 if smooth else 40) and worst_z < (1e-2 if smooth else 1e-4) and pool_flips <= (2000 if smooth else 40), \
         f"{flips} ReLU decisions differ, largest |z| there {worst_z:.2e}; {pool_flips} pool decisions differ"
