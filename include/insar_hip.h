@@ -201,6 +201,11 @@ int insar_bn_relu_apply(const InsarAct* y, const float* scale, const float* shif
                         const float* gate /*[B][C] or null*/, const InsarAct* dst, int32_t relu,
                         void* stream);
 
+/* the same pass for an encoder block, writing the 2x2 max-pool (:106-109) of dst as well: pooled is the
+ * (B, H/2, W/2, C) slice; identical to insar_bn_relu_apply followed by insar_maxpool2_fwd, one read less. */
+int insar_bn_relu_apply_pool(const InsarAct* y, const float* scale, const float* shift, const float* gate,
+                             const InsarAct* dst, const InsarAct* pooled, int32_t relu, void* stream);
+
 /* ---- SELayer (:45-72) ----------------------------------------------------------------------------
  * squeeze: partial sums of mask and mask*y, mask = (y*scale+shift > 0), over `rows_per_part` consecutive
  *   image rows: part[B][P][2][C], P = ceil(H / rows_per_part). */

@@ -106,6 +106,7 @@ _SIGNATURES = {
     "insar_colsum_partial": [_P, _P, _L, _I, _I, _P],
     "insar_bn_finalize": [C.POINTER(InsarBnFinalize), _P],
     "insar_bn_relu_apply": [_AP, _P, _P, _P, _AP, _I, _P],
+    "insar_bn_relu_apply_pool": [_AP, _P, _P, _P, _AP, _AP, _I, _P],
     "insar_se_squeeze": [_AP, _P, _P, _P, _I, _I, _P],
     "insar_se_excite": [C.POINTER(InsarSeFwd), _P],
     "insar_bnrelu_bwd_reduce": [_AP, _AP, _P, _P, _P, _I, _I, _P],

@@ -116,8 +116,14 @@ __device__ __forceinline__ void lds_dma16_untracked(const char* gsrc, uint32_t l
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
+// The barrier that ends a K step does two jobs: it publishes the slab the waves have just waited for (RAW, the
+// vmcnt part) and it FREES the slab they have just read for the next LDS-DMA (WAR). hipcc sinks the tail MFMAs of
+// a step and the lgkmcnt wait of their ds_reads below a raw s_barrier, so a wave could pass the barrier with its
+// last reads still queued in the LDS pipe while a faster wave's DMA was already on its way to the same slot: seen
+// as one stale MFMA fragment in ~1e-3 of the 64x64 weight-gradient launches when the DMA path was otherwise idle
+// (tools/debug_race.py). Hence lgkmcnt(0) BEFORE every such barrier.
 __device__ __forceinline__ void dma_drain_and_barrier() {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 }
 

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(C6_THREADS, 1) void conv3x3_c64_kernel(C64Args a) {
 
     // the prefetched rows must have landed before any wave starts the next tile (they had this tile's
     // whole compute phase); the previous tile's stores are long done, so the wait is free.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // lgkmcnt: see common.h, dma_drain_and_barrier
 
     epilogue(t);
     __builtin_amdgcn_s_barrier();

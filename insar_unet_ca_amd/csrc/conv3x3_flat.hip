@@ -66,7 +66,7 @@ struct FlatCfg {
 
 template <int N>
 __device__ __forceinline__ void fl_wait_and_barrier() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");   // lgkmcnt: see common.h, dma_drain_and_barrier
   __builtin_amdgcn_s_barrier();
 }
 

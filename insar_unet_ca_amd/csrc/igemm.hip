@@ -82,7 +82,7 @@ struct IgemmCfg {
 // drain the LDS-DMA queue down to N outstanding per wave, then meet the other waves
 template <int N>
 __device__ __forceinline__ void dma_wait_and_barrier() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");   // lgkmcnt: see common.h, dma_drain_and_barrier
   __builtin_amdgcn_s_barrier();
 }
 

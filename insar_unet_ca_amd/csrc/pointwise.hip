@@ -501,6 +501,74 @@ extern "C" int insar_bn_relu_apply(const InsarAct* y, const float* scale, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// z = relu(y*scale + shift) * gate AND its 2x2 max-pool in one pass (encoder blocks: :96-97 followed by
+// MaxPool2d(2) :106-109). A work-group takes two image rows; a thread a 2x2 window of one channel chunk:
+// four loads, four stores of z, one store of the window maximum. Rounding to the storage type is monotone,
+// so max-then-round equals the max-pool of the stored z bit for bit.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void bn_relu_apply_pool_kernel(ActView y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                          const float* __restrict__ gate, ActView dst, ActView pooled, int relu) {
+  constexpr int CH = Chunk<T>::N;
+  const int cpp = y.c_len / CH;
+  const int Hp = y.H / 2, Wp2 = y.W / 2;
+  const int rows = y.B * Hp;
+  const int cc = threadIdx.x % cpp, wstep = blockDim.x / cpp;          // host guarantees blockDim % cpp == 0
+  float sc[CH], sh[CH], gt[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { sc[j] = scale[cc * CH + j]; sh[j] = shift[cc * CH + j]; gt[j] = 1.f; }
+  int n_loaded = -1;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int n = r / Hp, h2 = r - n * Hp;
+    if (gate && n != n_loaded) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) gt[j] = gate[(int64_t)n * y.c_len + cc * CH + j];
+      n_loaded = n;
+    }
+    for (int w2 = threadIdx.x / cpp; w2 < Wp2; w2 += wstep) {
+      uint4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = *chunk_ptr<T>(y, n, 2 * h2 + (q >> 1), 2 * w2 + (q & 1), cc);
+      float m[CH];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float f[CH];
+        Chunk<T>::unpack(v[q], f);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const float z = fmaf(f[j], sc[j], sh[j]);
+          f[j] = (relu ? fmaxf(z, 0.f) : z) * gt[j];
+          m[j] = q == 0 ? f[j] : fmaxf(m[j], f[j]);
+        }
+        *chunk_ptr_w<T>(dst, n, 2 * h2 + (q >> 1), 2 * w2 + (q & 1), cc) = Chunk<T>::pack(f);
+      }
+      *chunk_ptr_w<T>(pooled, n, h2, w2, cc) = Chunk<T>::pack(m);
+    }
+  }
+}
+
+extern "C" int insar_bn_relu_apply_pool(const InsarAct* y, const float* scale, const float* shift, const float* gate,
+                                        const InsarAct* dst, const InsarAct* pooled, int32_t relu, void* stream) {
+  int rc;
+  if ((rc = insar_check_act(y, "insar_bn_relu_apply_pool", "y"))) return rc;
+  if ((rc = insar_check_act(dst, "insar_bn_relu_apply_pool", "dst"))) return rc;
+  if ((rc = insar_check_act(pooled, "insar_bn_relu_apply_pool", "pooled"))) return rc;
+  if ((rc = check_same_grid(y, dst, "insar_bn_relu_apply_pool"))) return rc;
+  if (!scale || !shift) INSAR_FAIL(INSAR_E_ARG, "insar_bn_relu_apply_pool: null scale/shift");
+  if ((y->H & 1) || (y->W & 1) || pooled->B != y->B || pooled->H != y->H / 2 || pooled->W != y->W / 2 ||
+      pooled->c_len != y->c_len || pooled->dtype != y->dtype)
+    INSAR_FAIL(INSAR_E_SHAPE, "insar_bn_relu_apply_pool: pooled slice must be (B, H/2, W/2, C) of an even grid");
+  const int ch = y->dtype == INSAR_BF16 ? 8 : 4;
+  if (PW_THREADS % (y->c_len / ch)) INSAR_FAIL(INSAR_E_SHAPE, "insar_bn_relu_apply_pool: C=%d unsupported", y->c_len);
+  int grid = insar_grid_cap((int64_t)y->B * (y->H / 2));
+  hipStream_t s = (hipStream_t)stream;
+  if (y->dtype == INSAR_BF16) hipLaunchKernelGGL(bn_relu_apply_pool_kernel<bf16_t>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*y), scale, shift, gate, make_view(*dst), make_view(*pooled), relu);
+  else hipLaunchKernelGGL(bn_relu_apply_pool_kernel<float>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*y), scale, shift, gate, make_view(*dst), make_view(*pooled), relu);
+  INSAR_CHECK_LAUNCH("insar_bn_relu_apply_pool");
+  return INSAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Row reductions. Both produce part[(n*H + h)][2][C] per-row partial sums over w:
 //   se_squeeze      : q0 = mask,          q1 = mask * y          (mask = y*scale+shift > 0)
 //   bnrelu_bwd_reduce: q0 = dout * mask,  q1 = dout * mask * y

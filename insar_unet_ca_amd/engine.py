@@ -371,14 +371,17 @@ class ConvBN:
         self.y = Act.alloc(B, H, W, self.cout, ctx.dtype, ctx.device)           # raw conv output (no bias)
         # large grids: flat-padded kernel (A rows shared by the three dx taps); else the per-tap implicit GEMM
         # 64 -> 64 channels in bf16: persistent register-weight kernel (forward and input gradient)
-        self.c64 = (not self.small) and bool(call("insar_conv3x3_c64_ok", x.ref, self.cout)) \
-            and os.environ.get("INSAR_C64", "1") != "0"
+        c64_mode = os.environ.get("INSAR_C64", "1")           # diagnostic: 0 = off, fwd / bwd = that direction only
+        self.c64 = (not self.small) and bool(call("insar_conv3x3_c64_ok", x.ref, self.cout)) and c64_mode != "0"
+        self.c64_fwd, self.c64_bwd = self.c64 and c64_mode != "bwd", self.c64 and c64_mode != "fwd"
         self.flat_fwd = (not self.small) and not self.c64 and bool(call("insar_conv3x3_flat_ok", x.ref, self.cout))
         self.flat_bwd = (not self.small) and not self.c64 and bool(call("insar_conv3x3_flat_ok", x.ref, self.cin))
         if self.small:
             self.stat_rows = call("insar_conv3x3_small_fwd_rows", x.ref, self.y.ref)
-        elif self.c64:
+        elif self.c64_fwd:
             self.stat_rows = call("insar_conv3x3_c64_rows", x.ref)
+        elif self.c64:
+            self.stat_rows = call("insar_igemm_num_mtiles", self.M, self.cout)
         elif self.flat_fwd:
             self.stat_rows = call("insar_conv3x3_flat_num_mtiles", x.ref)
         else:
@@ -408,8 +411,11 @@ class ConvBN:
         if self.small:
             w = self.conv.weight.detach()
             call("insar_conv3x3_small_fwd", self.x.ref, ptr(w), self.y.ref, ptr(self.stats) if training else 0, s)
-        elif self.c64:
+        elif self.c64_fwd:
             _conv3x3_c64(self.x, self.y, self.w.fwd(), 0, self.stats if training else None)
+        elif self.c64:
+            _igemm(self.x, self.y, self.w.fwd(), self.cout, self.x.H, self.x.W, 1, _TAPS3, 0,
+                   stats=self.stats if training else None)
         elif self.flat_fwd:
             _conv3x3_flat(self.x, self.y, self.w.fwd(), 0, self.stats if training else None)
         else:
@@ -429,7 +435,11 @@ class ConvBN:
         d.scale, d.shift, d.mean, d.invstd = ptr(self.scale), ptr(self.shift), ptr(self.mean), ptr(self.invstd)
         call("insar_bn_finalize", C.byref(d), s)
 
-    def apply(self, dst: Act, gate: Optional[torch.Tensor]) -> None:
+    def apply(self, dst: Act, gate: Optional[torch.Tensor], pooled: Optional[Act] = None) -> None:
+        if pooled is not None:          # encoder block: the 2x2 max-pool of dst comes out of the same pass
+            call("insar_bn_relu_apply_pool", self.y.ref, ptr(self.scale), ptr(self.shift), ptr(gate), dst.ref,
+                 pooled.ref, 1, _lib.stream_ptr())
+            return
         call("insar_bn_relu_apply", self.y.ref, ptr(self.scale), ptr(self.shift), ptr(gate), dst.ref, 1,
              _lib.stream_ptr())
 
@@ -474,8 +484,10 @@ class ConvBN:
         if dx is not None:
             if self.small:
                 raise _lib.InsarError(f"{self.name}: input gradient of the direct first-layer conv is not provided")
-            if self.c64:
+            if self.c64_bwd:
                 _conv3x3_c64(self.dy, dx, self.w.dgrad(), 1, None)
+            elif self.c64:
+                _igemm(self.dy, dx, self.w.dgrad(), self.cin, H, W, 1, _TAPS3_DGRAD, 0)
             elif self.flat_bwd:
                 _conv3x3_flat(self.dy, dx, self.w.dgrad(), 1, None)
             else:
@@ -523,6 +535,7 @@ class DoubleConvPlan:
 
     def __init__(self, ctx: Ctx, mod, x: Act, out: Act, name: str):
         self.ctx, self.mod, self.x, self.out, self.name = ctx, mod, x, out, name
+        self.pool_out: Optional[Act] = None      # set by the plan for encoder blocks: MaxPool2d(2) of `out`
         seq = mod.double_conv
         self.u1 = ConvBN(ctx, seq[0], seq[1], x, name + ".0")
         self.z1 = Act.alloc(x.B, x.H, x.W, self.u1.cout, ctx.dtype, ctx.device)
@@ -555,9 +568,9 @@ class DoubleConvPlan:
             d.w1, d.w2 = ptr(se.fc1.weight.detach()), ptr(se.fc2.weight.detach())
             d.sq, d.hid, d.gate = ptr(se.sq), ptr(se.hid), ptr(se.gate)
             call("insar_se_excite", C.byref(d), s)
-            u2.apply(self.out, se.gate)
+            u2.apply(self.out, se.gate, self.pool_out)
         else:
-            self.u2.apply(self.out, None)
+            self.u2.apply(self.out, None, self.pool_out)
 
     def backward(self, dout: Act, sink: GradSink, training: bool, dx: Optional[Act]) -> None:
         if self.dz1 is None:
@@ -699,6 +712,8 @@ class UNetPlan:
             xin = self.xin if l == 0 else self.pooled[l - 1]
             out = self.cat[l].slice(0, widths[l]) if l < 4 else self.x5
             self.enc.append(DoubleConvPlan(ctx, enc_mods[l], xin, out, enc_names[l]))
+            if l < 4:
+                self.enc[l].pool_out = self.pooled[l]
         ups = [net.up1, net.up2, net.up3, net.up4]
         convs = [net.conv1, net.conv2, net.conv3, net.conv4]
         self.up: List[UpPlan] = []
@@ -748,9 +763,7 @@ class UNetPlan:
         self.weightset.refresh()          # all GEMM-layout weight copies in one launch when the masters moved
         pack_input(x, self.xin)
         for l in range(5):
-            self.enc[l].forward(training)
-            if l < 4:
-                call("insar_maxpool2_fwd", self.enc[l].out.ref, self.pooled[l].ref, s())
+            self.enc[l].forward(training)          # levels 0-3 write their max-pool too (pool_out)
         for i in range(4):
             self.up[i].forward()
             self.dconv[i].forward(training)

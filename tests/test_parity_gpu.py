@@ -265,6 +265,29 @@ def test_conv_transpose_against_golden_and_float64(dev, dtype, golden):
     check_summary(g2, "convT_128_64/step0/grad/bias", sink.view(mod.bias), tol)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_apply_with_fused_maxpool_is_bitwise_the_two_pass_result(dev, dtype):
+    """insar_bn_relu_apply_pool == insar_bn_relu_apply followed by insar_maxpool2_fwd, bit for bit (rounding to
+    the storage type is monotone, so max-then-round equals the pool of the rounded values)."""
+    from insar_unet_ca_amd import _lib, engine
+    from insar_unet_ca_amd._lib import call, ptr
+    b, c, h, w = 3, 128, 12, 20
+    ya = _act_from(cf.make_input((b, c, h, w), 0.8), dtype, dev)
+    scale = cf.fill_tensor("weight", (c,), 2).to(dev).contiguous()
+    shift = cf.fill_tensor("bias", (c,), 3).to(dev).contiguous()
+    gate = torch.sigmoid(cf.make_grad((b, c))).to(dev).contiguous()
+    s = _lib.stream_ptr()
+    two = engine.Act.alloc(b, h, w, c, dtype, dev)
+    two_p = engine.Act.alloc(b, h // 2, w // 2, c, dtype, dev)
+    call("insar_bn_relu_apply", ya.ref, ptr(scale), ptr(shift), ptr(gate), two.ref, 1, s)
+    call("insar_maxpool2_fwd", two.ref, two_p.ref, s)
+    one = engine.Act.alloc(b, h, w, 2 * c, dtype, dev)             # written as a channel slice of a wider buffer
+    one_p = engine.Act.alloc(b, h // 2, w // 2, c, dtype, dev)
+    call("insar_bn_relu_apply_pool", ya.ref, ptr(scale), ptr(shift), ptr(gate), one.slice(0, c).ref, one_p.ref, 1, s)
+    assert torch.equal(one.slice(0, c).nchw(), two.nchw()) and torch.equal(one_p.nchw(), two_p.nchw())
+    assert float(one.slice(c, c).nchw().abs().max()) == 0.0 and _halo_abs(one_p) == 0.0
+
+
 def test_maxpool_golden_with_ties(dev, golden):
     import insar_unet_ca_amd as iu
     g2 = golden("g2_resample")
@@ -876,6 +899,30 @@ def test_bf16_training_curve_tracks_fp32_reference(dev, golden):
 # ------------------------------------------------------------------------------------------------
 # full BASELINE configuration (config 2: bf16, 16 x 2 x 256 x 256): size-independent properties
 # ------------------------------------------------------------------------------------------------
+def test_step_reproducible_over_many_runs_with_side_stream(dev):
+    """Race screen for the two-stream step (weight gradients beside the dgrad chain): 150 repeats of fwd+bwd on
+    fixed weights must give ONE set of gradient bits. (Regression: a wave passed the K-step barrier of the 64x64
+    weight-gradient kernel with LDS reads still queued and ~1e-3 of the launches picked up one fragment of the
+    NEXT slab; csrc/common.h, dma_drain_and_barrier.)"""
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd.data import make_batch
+    torch.manual_seed(0)
+    net = iu.UNet(2, 2, True, compute_dtype=torch.bfloat16).to(dev).train()
+    crit = iu.DiceCELoss(ignore_index=255)
+    x, y = make_batch(0, 16, 256)
+    x, y = x.to(dev), y.to(dev)
+    plan = net._plan(x)
+    seen = set()
+    for _ in range(150):
+        for p in net.parameters():
+            p.grad = None
+        loss = crit(net(x), y)
+        loss.backward()
+        flat = plan.sink.flat()
+        seen.add((int(flat.view(torch.int32).to(torch.int64).sum()), float(loss)))
+    assert len(seen) == 1, f"{len(seen)} distinct gradient checksums over 150 identical steps"
+
+
 def test_full_size_properties_bf16(dev):
     import insar_unet_ca_amd as iu
     from insar_unet_ca_amd.data import make_batch
