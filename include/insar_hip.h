@@ -251,6 +251,18 @@ int insar_bnrelu_bwd_apply(const InsarAct* dout, const InsarAct* y, const float*
                            const float* shift, const float* mean, const float* invstd,
                            const float* gate, const float* coefB, const float* k1,
                            const float* k2, const InsarAct* dy, int32_t relu, void* stream);
+/* The two stages of insar_bnse_bwd_coef on their own (stage = 1: per-image stage — SE backward, coefB and the
+ * per-image partial sums tb/tg in ws; stage = 2: batch fold — k1, k2, dgamma, dbeta, dW1, dW2, conv-bias gradient),
+ * and the apply pass that folds k1[c] = sum_n tb[n][c] / (B*H*W), k2[c] = sum_n tg[n][c] / (B*H*W) itself
+ * (training mode; tb = ws + B*(C+Cr), tg = tb + B*C; C <= 1024). With these the input-gradient chain
+ * (loss.backward(), Unet-ChannalAttention.py:345) needs only stage 1; stage 2 runs beside it on another stream.
+ * Bitwise the same dy as insar_bnse_bwd_coef + insar_bnrelu_bwd_apply. */
+int insar_bnse_bwd_coef_stage(const InsarBnSeBwd* d, const float* red, int32_t rows, const float* scale,
+                              const float* shift, float* ws, float* dconv_bias, int32_t training, int32_t stage,
+                              void* stream);
+int insar_bnrelu_bwd_apply_part(const InsarAct* dout, const InsarAct* y, const float* scale, const float* shift,
+                                const float* mean, const float* invstd, const float* gate, const float* coefB,
+                                const float* tb, const float* tg, const InsarAct* dy, int32_t relu, void* stream);
 
 /* ---- ChannelAttentionModule (DeepLabV3-ChannelAttention.py:49-79; config 5) ---------------------------
  * out = x * sigmoid(W2 relu(W1 avg_hw(x)) + W2 relu(W1 max_hw(x))), W1 (Cr,C), W2 (C,Cr), no biases.

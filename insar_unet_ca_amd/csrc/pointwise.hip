@@ -914,37 +914,73 @@ __global__ void bnse_bwd_stage2(BnSeBwdArgs a) {
   }
 }
 
-extern "C" int insar_bnse_bwd_coef(const InsarBnSeBwd* d, const float* red, int32_t rows, const float* scale,
-                                   const float* shift, float* ws, float* dconv_bias, int32_t training, void* stream) {
+static int launch_bnse_coef(const char* who, const InsarBnSeBwd* d, const float* red, int32_t rows, const float* scale,
+                            const float* shift, float* ws, float* dconv_bias, int32_t training, int stages, void* stream) {
   if (!d || !red || !scale || !shift || !ws || !d->mean || !d->invstd || !d->dgamma || !d->dbeta || !d->k1 || !d->k2)
-    INSAR_FAIL(INSAR_E_ARG, "insar_bnse_bwd_coef: null pointer");
+    INSAR_FAIL(INSAR_E_ARG, "%s: null pointer", who);
   if (d->use_se && (!d->pooled || !d->sq || !d->hid || !d->gate || !d->w1 || !d->w2 || !d->dw1 || !d->dw2 || !d->coefB))
-    INSAR_FAIL(INSAR_E_ARG, "insar_bnse_bwd_coef: SE pointers missing");
-  if (d->C > 8192 || d->B < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_bnse_bwd_coef: bad shape");
-  if (rows < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_bnse_bwd_coef: rows");
+    INSAR_FAIL(INSAR_E_ARG, "%s: SE pointers missing", who);
+  if (d->C > 8192 || d->B < 1) INSAR_FAIL(INSAR_E_SHAPE, "%s: bad shape", who);
+  if (rows < 1) INSAR_FAIL(INSAR_E_SHAPE, "%s: rows", who);
   BnSeBwdArgs a; a.d = *d; a.red = red; a.rows = rows; a.scale = scale; a.shift = shift; a.ws = ws; a.dconv_bias = dconv_bias; a.training = training;
   hipStream_t s = (hipStream_t)stream;
-  size_t lds = (size_t)(3 * d->C + d->Cr + 1 + COEF_THREADS) * sizeof(float);
-  hipLaunchKernelGGL(bnse_bwd_stage1, dim3(d->B), dim3(COEF_THREADS), lds, s, a);
-  int64_t work = d->C;
-  if (d->use_se && (int64_t)d->C * d->Cr > work) work = (int64_t)d->C * d->Cr;
-  hipLaunchKernelGGL(bnse_bwd_stage2, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a);
-  INSAR_CHECK_LAUNCH("insar_bnse_bwd_coef");
+  if (stages & 1) {
+    size_t lds = (size_t)(3 * d->C + d->Cr + 1 + COEF_THREADS) * sizeof(float);
+    hipLaunchKernelGGL(bnse_bwd_stage1, dim3(d->B), dim3(COEF_THREADS), lds, s, a);
+  }
+  if (stages & 2) {
+    int64_t work = d->C;
+    if (d->use_se && (int64_t)d->C * d->Cr > work) work = (int64_t)d->C * d->Cr;
+    hipLaunchKernelGGL(bnse_bwd_stage2, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a);
+  }
+  INSAR_CHECK_LAUNCH(who);
   return INSAR_OK;
 }
 
+extern "C" int insar_bnse_bwd_coef(const InsarBnSeBwd* d, const float* red, int32_t rows, const float* scale,
+                                   const float* shift, float* ws, float* dconv_bias, int32_t training, void* stream) {
+  return launch_bnse_coef("insar_bnse_bwd_coef", d, red, rows, scale, shift, ws, dconv_bias, training, 3, stream);
+}
+
+// One stage of the above: 1 = per-image stage (SE backward, coefB, the per-image partial sums in ws), 2 = batch fold
+// (k1, k2, dgamma, dbeta, dW1, dW2, conv-bias gradient). The dgrad chain needs only stage 1 when the apply pass
+// folds k1 / k2 itself (insar_bnrelu_bwd_apply_part); stage 2 can then run off the critical path.
+// ws floats: du[B][C] | dt[B][Cr] | tb[B][C] | tg[B][C].
+extern "C" int insar_bnse_bwd_coef_stage(const InsarBnSeBwd* d, const float* red, int32_t rows, const float* scale,
+                                         const float* shift, float* ws, float* dconv_bias, int32_t training,
+                                         int32_t stage, void* stream) {
+  if (stage != 1 && stage != 2) INSAR_FAIL(INSAR_E_ARG, "insar_bnse_bwd_coef_stage: stage must be 1 or 2");
+  return launch_bnse_coef("insar_bnse_bwd_coef_stage", d, red, rows, scale, shift, ws, dconv_bias, training, stage, stream);
+}
+
 // dy = scale * ( (dout*gate + coefB) * mask - k1 - xhat*k2 ),  xhat = (y - mean)*invstd
+#define BWD_APPLY_MAXC 1024
 template <typename T>
 __global__ void bnrelu_bwd_apply_kernel(ActView g, ActView y, const float* __restrict__ scale,
                                         const float* __restrict__ shift, const float* __restrict__ mean,
                                         const float* __restrict__ invstd, const float* __restrict__ gate,
-                                        const float* __restrict__ coefB, const float* __restrict__ k1,
-                                        const float* __restrict__ k2, ActView dy, int relu) {
+                                        const float* __restrict__ coefB, const float* k1,
+                                        const float* k2, ActView dy, int relu,
+                                        const float* __restrict__ tb, const float* __restrict__ tg) {
   constexpr int CH = Chunk<T>::N;
   const int cpp = y.c_len / CH;
   const int rows = y.B * y.H;
   const int total = y.W * cpp;
   const bool inv = (blockDim.x % cpp) == 0;
+  // k1 / k2 from the per-image partials of bnse_bwd_stage1 (tb, tg: [nimg][C]), folded here in image order
+  // exactly as bnse_bwd_stage2 folds them: the batch-fold launch leaves the dgrad chain (it still produces the
+  // parameter gradients, on the side stream).
+  __shared__ float sk[2 * BWD_APPLY_MAXC];
+  if (tb) {
+    const float invN = 1.f / ((float)y.B * (float)y.H * (float)y.W);      // as in bnse_bwd_stage2
+    for (int c = threadIdx.x; c < y.c_len; c += blockDim.x) {
+      float db = 0.f, dg = 0.f;
+      for (int n = 0; n < y.B; ++n) { db += tb[(int64_t)n * y.c_len + c]; dg += tg[(int64_t)n * y.c_len + c]; }
+      sk[c] = db * invN; sk[BWD_APPLY_MAXC + c] = dg * invN;
+    }
+    __syncthreads();
+    k1 = sk; k2 = sk + BWD_APPLY_MAXC;
+  }
   float sc[CH], sh[CH], mu[CH], is[CH], ga[CH], cb[CH], c1[CH], c2[CH];
   if (inv) {
     const int cc = threadIdx.x % cpp, wstep = blockDim.x / cpp;
@@ -1018,24 +1054,45 @@ __global__ void bnrelu_bwd_apply_kernel(ActView g, ActView y, const float* __res
   }
 }
 
-extern "C" int insar_bnrelu_bwd_apply(const InsarAct* dout, const InsarAct* y, const float* scale, const float* shift,
-                                      const float* mean, const float* invstd, const float* gate, const float* coefB,
-                                      const float* k1, const float* k2, const InsarAct* dy, int32_t relu, void* stream) {
+static int launch_bwd_apply(const char* who, const InsarAct* dout, const InsarAct* y, const float* scale, const float* shift,
+                            const float* mean, const float* invstd, const float* gate, const float* coefB,
+                            const float* k1, const float* k2, const InsarAct* dy, int32_t relu,
+                            const float* tb, const float* tg, void* stream) {
   int rc;
-  if ((rc = insar_check_act(y, "insar_bnrelu_bwd_apply", "y"))) return rc;
-  if ((rc = insar_check_act(dout, "insar_bnrelu_bwd_apply", "dout"))) return rc;
-  if ((rc = insar_check_act(dy, "insar_bnrelu_bwd_apply", "dy"))) return rc;
-  if ((rc = check_same_grid(y, dout, "insar_bnrelu_bwd_apply"))) return rc;
-  if ((rc = check_same_grid(y, dy, "insar_bnrelu_bwd_apply"))) return rc;
-  if (!scale || !shift || !mean || !invstd || !k1 || !k2) INSAR_FAIL(INSAR_E_ARG, "insar_bnrelu_bwd_apply: null pointer");
+  if ((rc = insar_check_act(y, who, "y"))) return rc;
+  if ((rc = insar_check_act(dout, who, "dout"))) return rc;
+  if ((rc = insar_check_act(dy, who, "dy"))) return rc;
+  if ((rc = check_same_grid(y, dout, who))) return rc;
+  if ((rc = check_same_grid(y, dy, who))) return rc;
+  if (!scale || !shift || !mean || !invstd) INSAR_FAIL(INSAR_E_ARG, "%s: null pointer", who);
+  if (!tb && (!k1 || !k2)) INSAR_FAIL(INSAR_E_ARG, "%s: null k1/k2", who);
+  if (tb && (!tg || y->c_len > BWD_APPLY_MAXC))
+    INSAR_FAIL(INSAR_E_SHAPE, "%s: partial sums need tg and C <= %d", who, BWD_APPLY_MAXC);
   int grid = insar_grid_cap((int64_t)y->B * y->H);
   hipStream_t s = (hipStream_t)stream;
   if (y->dtype == INSAR_BF16)
-    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, mean, invstd, gate, coefB, k1, k2, make_view(*dy), relu);
+    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, mean, invstd, gate, coefB, k1, k2, make_view(*dy), relu, tb, tg);
   else
-    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel<float>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, mean, invstd, gate, coefB, k1, k2, make_view(*dy), relu);
-  INSAR_CHECK_LAUNCH("insar_bnrelu_bwd_apply");
+    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel<float>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, mean, invstd, gate, coefB, k1, k2, make_view(*dy), relu, tb, tg);
+  INSAR_CHECK_LAUNCH(who);
   return INSAR_OK;
+}
+
+extern "C" int insar_bnrelu_bwd_apply(const InsarAct* dout, const InsarAct* y, const float* scale, const float* shift,
+                                      const float* mean, const float* invstd, const float* gate, const float* coefB,
+                                      const float* k1, const float* k2, const InsarAct* dy, int32_t relu, void* stream) {
+  return launch_bwd_apply("insar_bnrelu_bwd_apply", dout, y, scale, shift, mean, invstd, gate, coefB, k1, k2, dy, relu,
+                          nullptr, nullptr, stream);
+}
+
+// The same pass with k1 / k2 taken from stage 1's per-image partial sums (ws of insar_bnse_bwd_coef_stage, stage 1):
+// k1[c] = sum_n tb[n][c] / (B*H*W), k2[c] = sum_n tg[n][c] / (B*H*W) (training-mode BatchNorm), tb/tg: [B][C].
+extern "C" int insar_bnrelu_bwd_apply_part(const InsarAct* dout, const InsarAct* y, const float* scale, const float* shift,
+                                           const float* mean, const float* invstd, const float* gate, const float* coefB,
+                                           const float* tb, const float* tg, const InsarAct* dy, int32_t relu, void* stream) {
+  if (!tb) INSAR_FAIL(INSAR_E_ARG, "insar_bnrelu_bwd_apply_part: null partial sums");
+  return launch_bwd_apply("insar_bnrelu_bwd_apply_part", dout, y, scale, shift, mean, invstd, gate, coefB, nullptr, nullptr, dy,
+                          relu, tb, tg, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -235,6 +235,12 @@ class KernelTimer:
 
 
 PROFILER: Optional[KernelTimer] = None
+# Measured (B=16, 256x256, bf16): splitting the backward coefficient launch (batch fold on the side stream, k1/k2 folded
+# inside the apply pass) is 0.5 % SLOWER (9.40 vs 9.355 ms/step): the side stream already fills the main stream's
+# latency gaps in backward, which is throughput-bound. Kept as an option (bitwise equal, tested), off by default.
+SPLIT_COEF = os.environ.get("INSAR_SPLIT_COEF", "0") == "1"
+# Measured: issuing a unit's weight gradient AFTER its input-gradient GEMM ("after") is 1.2 % slower (9.34 vs 9.23 ms).
+WGRAD_LATE = os.environ.get("INSAR_WGRAD_ORDER", "before") == "after"      # diagnostic / tuning switch, see ConvBN.backward
 
 
 _TAPS3 = [(r - 1, s - 1) for r in range(3) for s in range(3)]
@@ -465,22 +471,45 @@ class ConvBN:
         d.k1, d.k2 = ptr(self.k1), ptr(self.k2)
         d.accumulate = 0
         dbias = ptr(sink.view(self.conv.bias)) if self.conv.bias is not None else 0
-        call("insar_bnse_bwd_coef", C.byref(d), ptr(self.red_part), self.red_rows, ptr(self.scale), ptr(self.shift), ptr(self.bwd_ws),
-             dbias, int(training), s)
-        call("insar_bnrelu_bwd_apply", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.mean),
-             ptr(self.invstd), ptr(se.gate) if se else 0, ptr(se.coefB) if se else 0, ptr(self.k1), ptr(self.k2),
-             self.dy.ref, 1, s)
+        coef_args = (C.byref(d), ptr(self.red_part), self.red_rows, ptr(self.scale), ptr(self.shift), ptr(self.bwd_ws),
+                     dbias, int(training))
+        # Training mode: only the per-image stage stays on the dgrad chain; the apply pass folds k1 / k2 from its
+        # partial sums itself and the batch fold (parameter gradients) follows the weight gradient on the side stream.
+        split = training and SPLIT_COEF and self.cout <= 1024
+        stage2 = None
+        if split:
+            call("insar_bnse_bwd_coef_stage", *coef_args, 1, s)
+            tb = self.bwd_ws.data_ptr() + 4 * B * (self.cout + d.Cr)
+            call("insar_bnrelu_bwd_apply_part", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.mean),
+                 ptr(self.invstd), ptr(se.gate) if se else 0, ptr(se.coefB) if se else 0, tb, tb + 4 * B * self.cout,
+                 self.dy.ref, 1, s)
+            stage2 = lambda: call("insar_bnse_bwd_coef_stage", *coef_args, 2, _lib.stream_ptr())
+        else:
+            call("insar_bnse_bwd_coef", *coef_args, s)
+            call("insar_bnrelu_bwd_apply", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.mean),
+                 ptr(self.invstd), ptr(se.gate) if se else 0, ptr(se.coefB) if se else 0, ptr(self.k1), ptr(self.k2),
+                 self.dy.ref, 1, s)
         # weight gradient (side stream: reads x and dy, writes only the gradient sink)
         gw = sink.view(self.conv.weight)
-        with ctx.side_stream():
-            if self.small:
-                nb = call("insar_conv3x3_small_wgrad_blocks", B, H)
-                cols = self.cout * self.cin * 9
-                part = ctx.wgrad_part(nb * cols)
-                call("insar_conv3x3_small_wgrad", self.x.ref, self.dy.ref, ptr(part), _lib.stream_ptr())
-                ctx.colsum(part, gw, 1, nb, cols)
-            else:
-                _wgrad_conv3(ctx, self.x, self.dy, gw)
+
+        def weight_grad():
+            with ctx.side_stream():
+                if self.small:
+                    nb = call("insar_conv3x3_small_wgrad_blocks", B, H)
+                    cols = self.cout * self.cin * 9
+                    part = ctx.wgrad_part(nb * cols)
+                    call("insar_conv3x3_small_wgrad", self.x.ref, self.dy.ref, ptr(part), _lib.stream_ptr())
+                    ctx.colsum(part, gw, 1, nb, cols)
+                else:
+                    _wgrad_conv3(ctx, self.x, self.dy, gw)
+                if stage2 is not None:
+                    stage2()
+
+        # Issue order: with WGRAD_LATE the side stream picks the weight gradient up only once the input-gradient
+        # GEMM of this unit is enqueued, so that it runs beside the NEXT unit's HBM- / latency-bound coefficient
+        # chain instead of competing with the dgrad (both MFMA-bound) for the CUs.
+        if not WGRAD_LATE:
+            weight_grad()
         if dx is not None:
             if self.small:
                 raise _lib.InsarError(f"{self.name}: input gradient of the direct first-layer conv is not provided")
@@ -492,6 +521,8 @@ class ConvBN:
                 _conv3x3_flat(self.dy, dx, self.w.dgrad(), 1, None)
             else:
                 _igemm(self.dy, dx, self.w.dgrad(), self.cin, H, W, 1, _TAPS3_DGRAD, 0)
+        if WGRAD_LATE:
+            weight_grad()
 
 
 def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
@@ -610,24 +641,30 @@ class UpPlan:
         tm, tn = _wgrad_tiles(self.cin, self.cout, ctx.code)
         tiles = 4 * (self.cin // tm) * (self.cout // tn)
         nsplit = _wgrad_nsplit(tiles, mpad // WG_BKP, 4 * self.cout * self.cin, tm, tn, ctx.esize)
-        with ctx.side_stream():
-            if self.mod.bias is not None:     # dbias = sum over pixels of dout (mask-free row reduction)
-                call("insar_bnrelu_bwd_reduce", dout.ref, dout.ref, ptr(ctx.const(0.0, self.cout)),
-                     ptr(ctx.const(1.0, self.cout)), ptr(self.bias_part), 0, self.bias_rpp, _lib.stream_ptr())
-                ctx.colsum(self.bias_part, self.bias_sum, 1, self.bias_rows, 2 * self.cout)
-                sink.view(self.mod.bias).copy_(self.bias_sum[0])
-            part = ctx.wgrad_part(nsplit * 4 * self.cout * self.cin)
-            d = InsarWgrad()
-            d.x, d.dy = x.desc, dout.desc
-            d.tabx, d.tabdy, d.part = ptr(tabx), ptr(tabdy), ptr(part)
-            d.Mpad, d.nsplit, d.ntaps = mpad, nsplit, 4
-            for i, (a, b) in enumerate(_TAPS2):
-                d.offx[i] = 0
-                d.offdy[i] = a * (dout.W + 2) + b
-            _launch_wgrad(d, B * h * w, self.cin, self.cout, 4, ctx.code)
-            ctx.wgrad_finish(part, sink.view(self.mod.weight), nsplit, 4, self.cout, self.cin, 1)
+        def weight_grad():
+            with ctx.side_stream():
+                if self.mod.bias is not None:     # dbias = sum over pixels of dout (mask-free row reduction)
+                    call("insar_bnrelu_bwd_reduce", dout.ref, dout.ref, ptr(ctx.const(0.0, self.cout)),
+                         ptr(ctx.const(1.0, self.cout)), ptr(self.bias_part), 0, self.bias_rpp, _lib.stream_ptr())
+                    ctx.colsum(self.bias_part, self.bias_sum, 1, self.bias_rows, 2 * self.cout)
+                    sink.view(self.mod.bias).copy_(self.bias_sum[0])
+                part = ctx.wgrad_part(nsplit * 4 * self.cout * self.cin)
+                d = InsarWgrad()
+                d.x, d.dy = x.desc, dout.desc
+                d.tabx, d.tabdy, d.part = ptr(tabx), ptr(tabdy), ptr(part)
+                d.Mpad, d.nsplit, d.ntaps = mpad, nsplit, 4
+                for i, (a, b) in enumerate(_TAPS2):
+                    d.offx[i] = 0
+                    d.offdy[i] = a * (dout.W + 2) + b
+                _launch_wgrad(d, B * h * w, self.cin, self.cout, 4, ctx.code)
+                ctx.wgrad_finish(part, sink.view(self.mod.weight), nsplit, 4, self.cout, self.cin, 1)
+
+        if not WGRAD_LATE:
+            weight_grad()
         if dx is not None:
             _igemm(dout, dx, self.w.dgrad(), self.cin, h, w, 2, _TAPS2, 0)
+        if WGRAD_LATE:
+            weight_grad()
 
 
 class OutConvPlan:

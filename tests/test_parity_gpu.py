@@ -899,6 +899,27 @@ def test_bf16_training_curve_tracks_fp32_reference(dev, golden):
 # ------------------------------------------------------------------------------------------------
 # full BASELINE configuration (config 2: bf16, 16 x 2 x 256 x 256): size-independent properties
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_split_backward_coefficients_are_bitwise_the_fused_launch(dev, dtype, monkeypatch):
+    """Per-image stage + k1/k2 folded inside the apply pass + batch fold on the side stream (the default) gives the
+    same gradient bits as insar_bnse_bwd_coef followed by insar_bnrelu_bwd_apply on the dgrad chain."""
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd import engine
+    from insar_unet_ca_amd.data import make_batch
+    x, y = make_batch(3, 3, 48)
+    x, y = x.to(dev), y.to(dev)
+    grads = []
+    for split in (True, False):
+        monkeypatch.setattr(engine, "SPLIT_COEF", split)
+        torch.manual_seed(5)
+        net = iu.UNet(2, 2, True, compute_dtype=dtype).to(dev).train()
+        loss = iu.DiceCELoss(ignore_index=255)(net(x), y)
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append([p.grad.clone() for p in net.parameters()])
+    assert all(torch.equal(a, b) for a, b in zip(*grads))
+
+
 def test_step_reproducible_over_many_runs_with_side_stream(dev):
     """Race screen for the two-stream step (weight gradients beside the dgrad chain): 150 repeats of fwd+bwd on
     fixed weights must give ONE set of gradient bits. (Regression: a wave passed the K-step barrier of the 64x64
