@@ -257,7 +257,7 @@ static int launch_wgrad(WgradArgs& a, hipStream_t s) {
 // Tile extent along a channel dimension of C channels (the Cin x Cout tile of a launch is tile(Cin) x tile(Cout),
 // except that 256 is used only when BOTH dimensions allow it: 8 waves, 128 KB of LDS, half the DMA pieces per MFMA).
 extern "C" int insar_wgrad_tile(int32_t C, int32_t dtype) {
-  if (dtype != INSAR_BF16) return 64;
+  if (dtype != INSAR_BF16) return (C % 128) == 0 ? 128 : 64;      // fp32: 128 x 128 (8 waves) only when BOTH allow it
   return (C % 256) == 0 ? 256 : ((C % 128) == 0 ? 128 : 64);
 }
 
@@ -289,6 +289,9 @@ extern "C" int insar_wgrad(const InsarWgrad* d, void* stream) {
     if (n128) return launch_wgrad<bf16_t, 64, 128, 4>(a, s);
     return launch_wgrad<bf16_t, 64, 64, 4>(a, s);
   }
+  // fp32 (v_mfma_f32_16x16x4_f32): 128 x 128 tiles with 8 waves (wave tile 64 x 32: 6 LDS reads per 8 MFMAs
+  // instead of 4 per 4, half the DMA pieces per MFMA) where both channel counts are multiples of 128
+  if (tm >= 128 && tn >= 128) return launch_wgrad<float, 128, 128, 8>(a, s);
   return launch_wgrad<float, 64, 64, 4>(a, s);
 }
 
