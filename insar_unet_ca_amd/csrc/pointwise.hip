@@ -366,11 +366,25 @@ __global__ void bn_finalize_kernel(InsarBnFinalize d) {
   if (c == 0 && rl == 0 && d.training && d.num_batches_tracked) *d.num_batches_tracked += 1;
   if (d.training) {
     double s1 = 0.0, s2 = 0.0;
-    if (c < d.C)
-      for (int64_t r = rl; r < d.rows; r += 8) {     // fold the remaining partial rows: [rows][2][C]
-        s1 += (double)d.part[(r * 2 + 0) * d.C + c];
-        s2 += (double)d.part[(r * 2 + 1) * d.C + c];
+    if (c < d.C) {
+      // fold the remaining partial rows [rows][2][C]: four independent chains so that a thread's loads overlap
+      // (this launch sits between a conv and its BN/ReLU pass on the forward chain: it is pure latency)
+      double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+      int64_t r = rl;
+      for (; r + 24 < d.rows; r += 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a1[u] += (double)d.part[((r + 8 * u) * 2 + 0) * d.C + c];
+          a2[u] += (double)d.part[((r + 8 * u) * 2 + 1) * d.C + c];
+        }
       }
+      for (; r < d.rows; r += 8) {
+        a1[0] += (double)d.part[(r * 2 + 0) * d.C + c];
+        a2[0] += (double)d.part[(r * 2 + 1) * d.C + c];
+      }
+      s1 = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+      s2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
+    }
     fold[0][rl][cl] = s1; fold[1][rl][cl] = s2;
     __syncthreads();
   }
