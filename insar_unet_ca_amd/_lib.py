@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libinsar_hip.so")
+# INSAR_HIP_LIB points the loader at another build of the same ABI (A/B runs of kernel experiments)
+LIB_PATH = os.environ.get("INSAR_HIP_LIB") or os.path.join(_HERE, "libinsar_hip.so")
 
 F32, BF16 = 0, 1
 ABI_VERSION = 1
