@@ -101,7 +101,8 @@ typedef struct InsarIgemm {
  * (the tile height, 128 or 256 pixels, is chosen from M and N so that the grid fills the 256 CUs). */
 int insar_igemm_num_mtiles(int64_t M, int32_t N);
 int insar_igemm_tile_rows(int64_t M, int32_t N);
-int insar_igemm_tile_cols(int64_t M, int32_t N);   /* 128 or 64 output channels per tile */
+int insar_igemm_tile_cols(int64_t M, int32_t N);   /* 128 or 64 output channels per tile (any dtype) */
+int insar_igemm_tile_cols_dt(int64_t M, int32_t N, int32_t dtype);   /* + 256 (bf16, N % 256 == 0, >= 256 such tiles) */
 int insar_igemm(const InsarIgemm* d, void* stream);
 
 /* ---- 3x3 / stride-1 convolution over the flat padded pixel space (MFMA) -------------------------------

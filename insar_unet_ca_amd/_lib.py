@@ -87,6 +87,7 @@ _SIGNATURES = {
     "insar_igemm_num_mtiles": [_L, _I],
     "insar_igemm_tile_rows": [_L, _I],
     "insar_igemm_tile_cols": [_L, _I],
+    "insar_igemm_tile_cols_dt": [_L, _I, _I],
     "insar_igemm": [C.POINTER(InsarIgemm), _P],
     "insar_conv3x3_flat_ok": [_AP, _I],
     "insar_conv3x3_flat_num_mtiles": [_AP],
@@ -165,7 +166,7 @@ def load():
     return lib
 
 
-_COUNT_ONLY = {"insar_igemm_num_mtiles", "insar_igemm_tile_rows", "insar_igemm_tile_cols", "insar_wgrad_tile", "insar_conv3x3_flat_ok", "insar_conv3x3_flat_num_mtiles", "insar_conv3x3_c64_ok", "insar_conv3x3_c64_rows", "insar_conv3x3_small_wgrad_blocks", "insar_conv3x3_small_fwd_rows", "insar_conv1x1_out_bwd_blocks",
+_COUNT_ONLY = {"insar_igemm_num_mtiles", "insar_igemm_tile_rows", "insar_igemm_tile_cols", "insar_igemm_tile_cols_dt", "insar_wgrad_tile", "insar_conv3x3_flat_ok", "insar_conv3x3_flat_num_mtiles", "insar_conv3x3_c64_ok", "insar_conv3x3_c64_rows", "insar_conv3x3_small_wgrad_blocks", "insar_conv3x3_small_fwd_rows", "insar_conv1x1_out_bwd_blocks",
                "insar_ce_blocks"}
 
 

@@ -259,8 +259,9 @@ def _igemm(x: Act, y: Act, w: torch.Tensor, N: int, Ho: int, Wo: int, stride: in
     if PROFILER is not None:
         flops = 2.0 * x.B * Ho * Wo * N * x.c_len * len(taps)
         bm = call("insar_igemm_tile_rows", x.B * Ho * Wo, N)
-        tag = "igemm_kernel<%s, %d, %d, %d>" % ("float" if x.code == _lib.F32 else "bf16_t", bm,
-                                                call("insar_igemm_tile_cols", x.B * Ho * Wo, N), 3 if bm == 256 else 2)
+        bn = call("insar_igemm_tile_cols_dt", x.B * Ho * Wo, N, x.code)
+        tag = "igemm_kernel<%s, %d, %d, %d>" % ("float" if x.code == _lib.F32 else "bf16_t", bm, bn,
+                                                3 if bm == 256 and bn < 256 else 2)
         es = 2 if x.code == _lib.BF16 else 4      # operands each read once, output written once
         nbytes = es * (x.B * x.H * x.W * x.c_len + y.B * y.H * y.W * y.c_len + w.numel())
         PROFILER.run(tag, flops, lambda: call("insar_igemm", C.byref(d), _lib.stream_ptr()), nbytes)
