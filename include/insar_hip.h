@@ -146,6 +146,9 @@ typedef struct InsarWgrad {
 /* tile extent the kernel uses along a channel dimension of C channels: 64 | 128 | 256 (256 only when both
  * Cin and Cout allow it, otherwise capped at 128); needed by callers that size the split-K factor. */
 int insar_wgrad_tile(int32_t C, int32_t dtype);
+/* the (Cin, Cout) tile of a layer as (tile(Cin) << 16) | tile(Cout): 256x256 (8 waves), 128x128, 128x64, 64x128,
+ * 64x64 in bf16; 128x128 (8 waves) or 64x64 in fp32. */
+int insar_wgrad_tile_pair(int32_t Cin, int32_t Cout, int32_t dtype);
 int insar_wgrad(const InsarWgrad* d, void* stream);
 /* grad = sum_split part[...] re-laid out to the torch parameter layout.
  * layout 0: Conv2d (Co,Ci,kh,kw): grad[(co*Ci+ci)*ntaps + tap]

@@ -261,6 +261,21 @@ extern "C" int insar_wgrad_tile(int32_t C, int32_t dtype) {
   return (C % 256) == 0 ? 256 : ((C % 128) == 0 ? 128 : 64);
 }
 
+// The (Cin, Cout) tile insar_wgrad uses for a layer: bf16 256x256 (8 waves), 128x128, 128x64, 64x128, 64x64 (4 waves);
+// fp32 128x128 (8 waves) or 64x64.
+static void wgrad_tile_pair(int Cin, int Cout, int dtype, int& tm, int& tn) {
+  tm = insar_wgrad_tile(Cin, dtype); tn = insar_wgrad_tile(Cout, dtype);
+  if (dtype != INSAR_BF16) { if (!(tm == 128 && tn == 128)) tm = tn = 64; return; }
+  if (tm == 256 && tn == 256) return;
+  // (256 x 128 / 128 x 256 tiles with 8 waves were measured: no gain over 128 x 128 in the step, same-box A/B)
+  tm = tm > 128 ? 128 : tm; tn = tn > 128 ? 128 : tn;
+}
+extern "C" int insar_wgrad_tile_pair(int32_t Cin, int32_t Cout, int32_t dtype) {      // (tile(Cin) << 16) | tile(Cout)
+  int tm, tn;
+  wgrad_tile_pair(Cin, Cout, dtype, tm, tn);
+  return (tm << 16) | tn;
+}
+
 extern "C" int insar_wgrad(const InsarWgrad* d, void* stream) {
   if (!d || !d->x.ptr || !d->dy.ptr || !d->tabx || !d->tabdy || !d->part) INSAR_FAIL(INSAR_E_ARG, "insar_wgrad: null pointer");
   int rc;
@@ -280,18 +295,18 @@ extern "C" int insar_wgrad(const InsarWgrad* d, void* stream) {
   a.Cdy = d->dy.C; a.cdy_off = d->dy.c_off; a.Cout = Cout;
   for (int t = 0; t < 12; ++t) { a.offx[t] = t < d->ntaps ? d->offx[t] : 0; a.offdy[t] = t < d->ntaps ? d->offdy[t] : 0; }
   hipStream_t s = (hipStream_t)stream;
-  const int tm = insar_wgrad_tile(Cin, d->x.dtype), tn = insar_wgrad_tile(Cout, d->x.dtype);
+  int tm, tn;
+  wgrad_tile_pair(Cin, Cout, d->x.dtype, tm, tn);
   if (d->x.dtype == INSAR_BF16) {
     if (tm == 256 && tn == 256) return launch_wgrad<bf16_t, 256, 256, 8>(a, s);
-    const bool m128 = tm >= 128, n128 = tn >= 128;
-    if (m128 && n128) return launch_wgrad<bf16_t, 128, 128, 4>(a, s);
-    if (m128) return launch_wgrad<bf16_t, 128, 64, 4>(a, s);
-    if (n128) return launch_wgrad<bf16_t, 64, 128, 4>(a, s);
+    if (tm == 128 && tn == 128) return launch_wgrad<bf16_t, 128, 128, 4>(a, s);
+    if (tm == 128) return launch_wgrad<bf16_t, 128, 64, 4>(a, s);
+    if (tn == 128) return launch_wgrad<bf16_t, 64, 128, 4>(a, s);
     return launch_wgrad<bf16_t, 64, 64, 4>(a, s);
   }
   // fp32 (v_mfma_f32_16x16x4_f32): 128 x 128 tiles with 8 waves (wave tile 64 x 32: 6 LDS reads per 8 MFMAs
   // instead of 4 per 4, half the DMA pieces per MFMA) where both channel counts are multiples of 128
-  if (tm >= 128 && tn >= 128) return launch_wgrad<float, 128, 128, 8>(a, s);
+  if (tm == 128 && tn == 128) return launch_wgrad<float, 128, 128, 8>(a, s);
   return launch_wgrad<float, 64, 64, 4>(a, s);
 }
 

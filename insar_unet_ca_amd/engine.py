@@ -289,19 +289,15 @@ def _conv3x3_c64(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[tor
 
 def _wgrad_tiles(cin: int, cout: int, code: int):
     """(Cin, Cout) tile of the weight-gradient kernel (csrc/wgrad.hip: insar_wgrad_tile)."""
-    tm, tn = call("insar_wgrad_tile", cin, code), call("insar_wgrad_tile", cout, code)
-    if code != _lib.BF16:                 # fp32: 128 x 128 (8 waves) or 64 x 64
-        return (128, 128) if tm == 128 and tn == 128 else (64, 64)
-    if tm == 256 and tn == 256:
-        return 256, 256
-    return min(tm, 128), min(tn, 128)
+    pair = call("insar_wgrad_tile_pair", cin, cout, code)
+    return pair >> 16, pair & 0xffff
 
 
 def _launch_wgrad(d: InsarWgrad, M: int, cin: int, cout: int, ntaps: int, code: int) -> None:
     if PROFILER is not None:
         tm, tn = _wgrad_tiles(cin, cout, code)
         tag = "wgrad_kernel<%s, %d, %d, %d>" % ("float" if code == _lib.F32 else "bf16_t", tm, tn,
-                                                  8 if tm == 256 or (code == _lib.F32 and tm == 128) else 4)
+                                                  8 if max(tm, tn) == 256 or (code == _lib.F32 and tm == 128) else 4)
         PROFILER.run(tag, 2.0 * M * cin * cout * ntaps, lambda: call("insar_wgrad", C.byref(d), _lib.stream_ptr()))
         return
     call("insar_wgrad", C.byref(d), _lib.stream_ptr())

@@ -80,6 +80,8 @@ def _halo_abs(a):
     (64, 128, (4, 64, 128, 128)),    # 65536 pixels: 256-row tiles, N = 128
     (256, 512, (4, 256, 32, 32)),    # 256x256 weight-gradient tiles (8 waves) with split-K, two Cout tiles
     (64, 1024, (4, 64, 32, 32)),     # 4096 pixels x 1024 channels: the 256x64 tile choice
+    (256, 128, (2, 256, 16, 24)),    # weight gradient: Cin allows 256, Cout only 128 -> 128 x 128 tiles
+    (128, 256, (3, 128, 16, 16)),
     (64, 512, (2, 64, 128, 128)),    # forward N = 512 on 128 M tiles: 256 x 256 tiles (bf16)
     (256, 64, (4, 256, 128, 128)),   # input gradient N = 256 on 256 M tiles: 256 x 256 tiles (bf16)
 ])
