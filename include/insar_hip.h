@@ -150,6 +150,13 @@ int insar_wgrad_tile(int32_t C, int32_t dtype);
  * 64x64 in bf16; 128x128 (8 waves) or 64x64 in fp32. */
 int insar_wgrad_tile_pair(int32_t Cin, int32_t Cout, int32_t dtype);
 int insar_wgrad(const InsarWgrad* d, void* stream);
+/* The same slabs for a 3x3 / stride-1 / pad-1 convolution (Unet-ChannalAttention.py:81,84; tap = 3*ty + tx) from a
+ * kernel whose work-groups compute the three taps of a kernel row together: dy staged once per 64-pixel K step, x
+ * once with a one-pixel lead and tail, a third of the LDS-DMA pieces of insar_wgrad (which these layers are bound by).
+ * x (B,H,W,Cin), dy (B,H,W,Cout) on the same grid, part[nsplit][9][Cout][Cin]. insar_wgrad_conv3_tile returns
+ * (tile(Cin) << 16) | tile(Cout), or 0 when the layer needs insar_wgrad (not bf16, W % 64 != 0, 256-wide tiles). */
+int insar_wgrad_conv3_tile(const InsarAct* x, int32_t Cout);
+int insar_wgrad_conv3(const InsarAct* x, const InsarAct* dy, float* part, int32_t nsplit, void* stream);
 /* grad = sum_split part[...] re-laid out to the torch parameter layout.
  * layout 0: Conv2d (Co,Ci,kh,kw): grad[(co*Ci+ci)*ntaps + tap]
  * layout 1: ConvTranspose2d (Ci,Co,2,2): grad[(ci*Co+co)*ntaps + tap]

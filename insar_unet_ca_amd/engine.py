@@ -240,6 +240,7 @@ PROFILER: Optional[KernelTimer] = None
 # latency gaps in backward, which is throughput-bound. Kept as an option (bitwise equal, tested), off by default.
 SPLIT_COEF = os.environ.get("INSAR_SPLIT_COEF", "0") == "1"
 # Measured: issuing a unit's weight gradient AFTER its input-gradient GEMM ("after") is 1.2 % slower (9.34 vs 9.23 ms).
+WGRAD_ROWS = os.environ.get("INSAR_WGRAD_ROWS", "1") != "0"      # diagnostic: 0 = per-tap weight-gradient kernel everywhere
 WGRAD_LATE = os.environ.get("INSAR_WGRAD_ORDER", "before") == "after"      # diagnostic / tuning switch, see ConvBN.backward
 
 
@@ -309,13 +310,18 @@ def _rows_per_part(B: int, H: int) -> int:
     return max(1, (B * H) // 1024, -(-H // 64))
 
 
-def _wgrad_nsplit(tiles: int, ksteps: int, slab_floats: int = 0, tm: int = 128, tn: int = 128, esize: int = 2) -> int:
+def _wgrad_nsplit(tiles: int, ksteps: int, slab_floats: int = 0, tm: int = 128, tn: int = 128, esize: int = 2,
+                  taps_per_wg: int = 1) -> int:
     """Split-K factor for the weight-gradient GEMM. The grid is tiles*nsplit work-groups at two per CU
     (512 slots): pick the factor that minimises an estimate of
       GEMM time / (slot quantisation efficiency * main-loop share) + slab fold traffic."""
     lds = 2 * 64 * (tm + tn) * esize + 128            # WgradCfg::LDS_BYTES
+    if taps_per_wg == 3:
+        lds = 2 * (72 * tm + 64 * tn) * esize          # Wgrad3Cfg::LDS_BYTES
     slots = 256 * max(1, min(4, (160 * 1024) // lds))
-    flops_per_step = 2.0 * tm * tn * 64
+    if taps_per_wg == 3 and tm * tn >= 128 * 128:
+        slots = 256                                    # 8-wave work-groups, one per CU
+    flops_per_step = 2.0 * tm * tn * 64 * taps_per_wg
     best, best_t = 1, float("inf")
     for n in range(1, max(1, min(ksteps // 4, 256)) + 1):
         steps = -(-ksteps // n)
@@ -528,6 +534,21 @@ class ConvBN:
 def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
     B, H, W = x.B, x.H, x.W
     cin, cout = x.c_len, dy.c_len
+    pair = call("insar_wgrad_conv3_tile", x.ref, cout) if WGRAD_ROWS else 0
+    if pair:
+        # three taps of a kernel row per work-group (csrc/wgrad3.hip): a third of the operand staging
+        tm, tn = pair >> 16, pair & 0xffff
+        tiles = 3 * (cin // tm) * (cout // tn)
+        nsplit = _wgrad_nsplit(tiles, B * H * W // WG_BKP, 9 * cout * cin, tm, tn, ctx.esize, taps_per_wg=3)
+        part = ctx.wgrad_part(nsplit * 9 * cout * cin)
+        if PROFILER is not None:
+            tag = "wgrad3_kernel<%d, %d, %d>" % (tm, tn, 8 if tm == 128 and tn == 128 else 4)
+            PROFILER.run(tag, 2.0 * B * H * W * cin * cout * 9,
+                         lambda: call("insar_wgrad_conv3", x.ref, dy.ref, ptr(part), nsplit, _lib.stream_ptr()))
+        else:
+            call("insar_wgrad_conv3", x.ref, dy.ref, ptr(part), nsplit, _lib.stream_ptr())
+        ctx.wgrad_finish(part, grad, nsplit, 9, cout, cin, 0)
+        return
     tabx = ctx.pixel_table(B, H, W, 1, H, W, W + 3)      # taps move on x: tail = first interior pixel
     tabdy = ctx.pixel_table(B, H, W, 1, H, W, 0)         # tail = zero halo pixel
     mpad = tabx.numel()
@@ -542,7 +563,6 @@ def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
     for i, (ty, tx) in enumerate(_TAPS3):
         d.offx[i] = ty * (W + 2) + tx
         d.offdy[i] = 0
-    s = _lib.stream_ptr()
     _launch_wgrad(d, B * H * W, cin, cout, 9, ctx.code)
     ctx.wgrad_finish(part, grad, nsplit, 9, cout, cin, 0)
 

@@ -80,6 +80,8 @@ def mocked_abi(monkeypatch):
             return 64
         if name == "insar_wgrad_tile_pair":
             return (64 << 16) | 64
+        if name == "insar_wgrad_conv3_tile":
+            return 0
         if name in ("insar_conv3x3_flat_ok", "insar_conv3x3_flat_num_mtiles"):
             return 0
         if name == "insar_conv3x3_small_fwd_rows":

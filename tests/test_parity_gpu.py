@@ -82,6 +82,8 @@ def _halo_abs(a):
     (64, 1024, (4, 64, 32, 32)),     # 4096 pixels x 1024 channels: the 256x64 tile choice
     (256, 128, (2, 256, 16, 24)),    # weight gradient: Cin allows 256, Cout only 128 -> 128 x 128 tiles
     (128, 256, (3, 128, 16, 16)),
+    (64, 64, (2, 64, 32, 64)),       # W % 64 == 0: row-of-taps weight gradient, 64 x 64 tile (bf16)
+    (128, 128, (2, 128, 24, 128)),   # row-of-taps weight gradient, 128 x 128 tile with 8 waves, two K steps per row
     (64, 512, (2, 64, 128, 128)),    # forward N = 512 on 128 M tiles: 256 x 256 tiles (bf16)
     (256, 64, (4, 256, 128, 128)),   # input gradient N = 256 on 256 M tiles: 256 x 256 tiles (bf16)
 ])
