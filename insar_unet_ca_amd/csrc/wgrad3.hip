@@ -8,8 +8,9 @@
 // tools/gemm_bench.py, 202 -> 97 us): here a K step of 64 CONSECUTIVE pixels of one image row stages dY once
 // (64 rows) and X once with a one-pixel lead and tail (66 rows of a 72-row slot; the zero halo of the padded NHWC
 // layout is the conv padding), 17 one-KB pieces per step instead of 48, and the dY fragments stay in registers for
-// the three taps. Needs W % 64 == 0 (a K step never leaves an image row), which holds for the 256^2 ... 64^2 levels;
-// everything else keeps the per-tap kernel. Same LDS image (pixel rows, XOR-swizzled on the DMA source side,
+// the three taps. Needs W % 64 == 0 (a K step is a piece of one image row) or W = 16 / 32 (a K step is 4 / 2 whole
+// image rows, whose X operand is still one contiguous run of <= 72 padded pixels): every level of the U-Net;
+// anything else keeps the per-tap kernel. Same LDS image (pixel rows, XOR-swizzled on the DMA source side,
 // ds_read_b64_tr_b16 transposing reads), same slab layout, same fold: bitwise reproducible.
 #include "common.h"
 
@@ -24,7 +25,8 @@ struct Wgrad3Args {
   const char* x; const char* dy; float* part;
   long long ksteps;
   int nsplit, steps_per_split;
-  int H, W, Wp, spr;            // spr = W / 64 K steps per image row
+  int H, W, Wp;
+  int spr, rpk, lw;             // K steps per image row (W >= 64) / image rows per K step (W < 64) / log2(W) (6 if W >= 64)
   int Cx, cx_off, Cin; int Cdy, cdy_off, Cout;
   int mtc, ntc;
 };
@@ -84,38 +86,37 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad3_kernel(Wgra
     const int sub = q / (W3_XR * Cfg::CPRX), row = (q / Cfg::CPRX) % W3_XR, pos = q % Cfg::CPRX;
     xrow_i[i] = row;
     xoff_i[i] = sub * Cfg::RBX + (pos ^ w3_swz<Cfg::RBX>(row)) * 16;
-    xok_i[i] = q < Cfg::XCHUNKS && row < W3_BKP + 2;
+    xok_i[i] = q < Cfg::XCHUNKS && row < W3_BKP + 2 * a.rpk;
   }
   int yrow_i[Cfg::NY], yoff_i[Cfg::NY];
 #pragma unroll
   for (int i = 0; i < Cfg::NY; ++i) {
     const int q = i * THREADS + tid;
     const int sub = q / (W3_BKP * Cfg::CPRY), row = (q / Cfg::CPRY) % W3_BKP, pos = q % Cfg::CPRY;
-    yrow_i[i] = row;
+    yrow_i[i] = row + 2 * (row >> a.lw);              // padded pixel offset of dY row `row` (halo pixels skipped)
     yoff_i[i] = sub * Cfg::RBY + (pos ^ w3_swz<Cfg::RBY>(row)) * 16;
   }
   const long long xpitch = (long long)a.Cx * ES, ypitch = (long long)a.Cdy * ES;
-  // X row r of a step <-> padded pixel p0 + (ty-1)*Wp - 1 + r ; dY row r <-> padded pixel p0 + r
+  // A K step is 64 interior pixels: a piece of one image row (W >= 64) or 64/W whole image rows (W = 16, 32). In the
+  // padded layout (rows of W+2 pixels) its X operand is ONE contiguous run: X row r <-> padded pixel
+  // p0 + (ty-1)*Wp - 1 + r, r < 64 + 2*rpk <= 72; dY row k <-> padded pixel p0 + k + 2*(k / W) (halo pixels skipped),
+  // and the X row of (dY row k, tap tx) is k + 2*(k / W) + tx.
   const char* xbase = a.x + ((long long)(ty - 1) * a.Wp - 1) * xpitch + ((long long)a.cx_off + mi * TM) * ES;
   const char* ybase = a.dy + ((long long)a.cdy_off + ni * TN) * ES;
 
-  // padded index of the first pixel of a K step (64 consecutive interior pixels of one image row), advanced step by
-  // step: +64 inside a row, +2 over the halo at a row end, +2 rows of halo at an image end (all wave-uniform)
-  int seg, hrow;
-  long long pnext;
+  // padded index of the first pixel of a K step, advanced step by step (all wave-uniform)
+  int seg, hrow, img;
   {
-    const int rowid = ks0 / a.spr;
-    seg = ks0 - rowid * a.spr;
-    const int n = rowid / a.H;
-    hrow = rowid - n * a.H;
-    pnext = ((long long)n * (a.H + 2) + hrow + 1) * a.Wp + seg * W3_BKP + 1;
+    const int g = ks0 / a.spr, gpi = a.H / a.rpk;       // row group (rpk image rows) and groups per image
+    seg = ks0 - g * a.spr;
+    img = g / gpi;
+    hrow = (g - img * gpi) * a.rpk;
   }
   auto next_pixel = [&]() -> long long {
-    const long long p = pnext;
-    pnext += W3_BKP;
+    const long long p = ((long long)img * (a.H + 2) + hrow + 1) * a.Wp + seg * W3_BKP + 1;
     if (++seg == a.spr) {
-      seg = 0; pnext += 2;
-      if (++hrow == a.H) { hrow = 0; pnext += 2 * a.Wp; }
+      seg = 0; hrow += a.rpk;
+      if (hrow >= a.H) { hrow = 0; ++img; }
     }
     return p;
   };
@@ -174,7 +175,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad3_kernel(Wgra
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const int sel = h ^ (kq & 1);
-            const int row = s * 32 + kq * 8 + sel * 4 + (r16 >> 2) + t3;      // X rows lead the dY rows by one pixel
+            const int k = s * 32 + kq * 8 + sel * 4 + (r16 >> 2);
+            const int row = k + 2 * (k >> a.lw) + t3;                         // X rows lead the dY rows by one pixel
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) {
               const int colw = (wm * (TM / 2) + mt * 16 + (r16 & 3) * 4) * 2;
@@ -232,11 +234,16 @@ static int launch_wgrad3(Wgrad3Args& a, hipStream_t s) {
 // (tile(Cin) << 16) | tile(Cout) of the row-of-taps kernel for this layer, or 0 when the per-tap kernel (insar_wgrad)
 // has to be used: bf16, image rows that are whole K steps, and a tile whose three accumulator sets fit the registers.
 extern "C" int insar_wgrad_conv3_tile(const InsarAct* x, int32_t Cout) {
-  if (!x || x->dtype != INSAR_BF16 || (x->W % W3_BKP) || x->c_len % 64 || Cout % 64) return 0;
+  if (!x || x->dtype != INSAR_BF16 || x->c_len % 64 || Cout % 64) return 0;
+  const bool rows_ok = (x->W % W3_BKP) == 0 || ((x->W == 16 || x->W == 32) && (x->H % (W3_BKP / x->W)) == 0);
+  if (!rows_ok) return 0;
   const int pair = insar_wgrad_tile_pair(x->c_len, Cout, x->dtype);
-  const int tm = pair >> 16, tn = pair & 0xffff;
-  if (tm > 128 || tn > 128) return 0;            // 256 x 256 tiles: three accumulator sets do not fit
-  return pair;
+  int tm = pair >> 16, tn = pair & 0xffff;
+  // three accumulator sets of a 256 x 256 tile do not fit the registers: 128 x 128 (8 waves) there; sharing the
+  // operands between the taps saves more staging than the wider tile did
+  if (tm > 128) tm = 128;
+  if (tn > 128) tn = 128;
+  return (tm << 16) | tn;
 }
 
 // part[split][tap][co][ci] (tap = 3*ty + tx, the layout insar_wgrad writes) for a 3x3 / stride-1 / pad-1 convolution:
@@ -249,14 +256,17 @@ extern "C" int insar_wgrad_conv3(const InsarAct* x, const InsarAct* dy, float* p
   if (x->B != dy->B || x->H != dy->H || x->W != dy->W) INSAR_FAIL(INSAR_E_SHAPE, "insar_wgrad_conv3: x/dy grids differ");
   if (x->dtype != dy->dtype) INSAR_FAIL(INSAR_E_DTYPE, "insar_wgrad_conv3: x/dy dtype differ");
   const int pair = insar_wgrad_conv3_tile(x, dy->c_len);
-  if (!pair) INSAR_FAIL(INSAR_E_SHAPE, "insar_wgrad_conv3: unsupported layer (bf16, W %% 64 == 0, tiles <= 128 only); use insar_wgrad");
+  if (!pair) INSAR_FAIL(INSAR_E_SHAPE, "insar_wgrad_conv3: unsupported layer (bf16; W %% 64 == 0, or W = 16 / 32 with whole K steps per image); use insar_wgrad");
   if (nsplit < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_wgrad_conv3: nsplit");
   Wgrad3Args a;
   a.x = (const char*)x->ptr; a.dy = (const char*)dy->ptr; a.part = part;
   a.ksteps = (long long)x->B * x->H * x->W / W3_BKP;
   a.nsplit = nsplit;
   a.steps_per_split = (int)((a.ksteps + nsplit - 1) / nsplit);
-  a.H = x->H; a.W = x->W; a.Wp = x->W + 2; a.spr = x->W / W3_BKP;
+  a.H = x->H; a.W = x->W; a.Wp = x->W + 2;
+  a.spr = x->W >= W3_BKP ? x->W / W3_BKP : 1;
+  a.rpk = x->W >= W3_BKP ? 1 : W3_BKP / x->W;
+  a.lw = x->W >= W3_BKP ? 6 : (x->W == 32 ? 5 : 4);
   a.Cx = x->C; a.cx_off = x->c_off; a.Cin = x->c_len;
   a.Cdy = dy->C; a.cdy_off = dy->c_off; a.Cout = dy->c_len;
   hipStream_t s = (hipStream_t)stream;
