@@ -299,7 +299,9 @@ def _launch_wgrad(d: InsarWgrad, M: int, cin: int, cout: int, ntaps: int, code: 
         tm, tn = _wgrad_tiles(cin, cout, code)
         tag = "wgrad_kernel<%s, %d, %d, %d>" % ("float" if code == _lib.F32 else "bf16_t", tm, tn,
                                                   8 if max(tm, tn) == 256 or (code == _lib.F32 and tm == 128) else 4)
-        PROFILER.run(tag, 2.0 * M * cin * cout * ntaps, lambda: call("insar_wgrad", C.byref(d), _lib.stream_ptr()))
+        es = 2 if code == _lib.BF16 else 4
+        nbytes = es * M * (cin + cout) * 1.0 + 4.0 * d.nsplit * ntaps * cout * cin
+        PROFILER.run(tag, 2.0 * M * cin * cout * ntaps, lambda: call("insar_wgrad", C.byref(d), _lib.stream_ptr()), nbytes)
         return
     call("insar_wgrad", C.byref(d), _lib.stream_ptr())
 
@@ -543,8 +545,10 @@ def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
         part = ctx.wgrad_part(nsplit * 9 * cout * cin)
         if PROFILER is not None:
             tag = "wgrad3_kernel<%d, %d, %d>" % (tm, tn, 8 if tm == 128 and tn == 128 else 4)
+            # algorithmic bytes: both operands read once, the split-K slabs written once
+            nbytes = ctx.esize * B * H * W * (cin + cout) + 4.0 * nsplit * 9 * cout * cin
             PROFILER.run(tag, 2.0 * B * H * W * cin * cout * 9,
-                         lambda: call("insar_wgrad_conv3", x.ref, dy.ref, ptr(part), nsplit, _lib.stream_ptr()))
+                         lambda: call("insar_wgrad_conv3", x.ref, dy.ref, ptr(part), nsplit, _lib.stream_ptr()), nbytes)
         else:
             call("insar_wgrad_conv3", x.ref, dy.ref, ptr(part), nsplit, _lib.stream_ptr())
         ctx.wgrad_finish(part, grad, nsplit, 9, cout, cin, 0)

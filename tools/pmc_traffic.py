@@ -17,7 +17,7 @@ def main():
     fa, wa = load(f, "FETCH_SIZE"), load(w, "WRITE_SIZE")
     res = {}
     for k in sorted(set(fa) | set(wa)):
-        if not any(t in k for t in ("igemm_kernel", "wgrad_kernel", "conv3x3_flat_kernel", "conv3x3_c64_kernel")):
+        if not any(t in k for t in ("igemm_kernel", "wgrad_kernel", "wgrad3_kernel", "conv3x3_flat_kernel", "conv3x3_c64_kernel")):
             continue
         fk = fa[k][0] / max(fa[k][1], 1); wk = wa[k][0] / max(wa[k][1], 1)
         res[k] = {"launches_profiled": fa[k][1], "FETCH_SIZE_KB_avg": round(fk, 1), "WRITE_SIZE_KB_avg": round(wk, 1),
