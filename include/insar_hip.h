@@ -154,8 +154,8 @@ int insar_wgrad(const InsarWgrad* d, void* stream);
  * kernel whose work-groups compute the three taps of a kernel row together: dy staged once per 64-pixel K step, x
  * once with a one-pixel lead and tail, a third of the LDS-DMA pieces of insar_wgrad (which these layers are bound by).
  * x (B,H,W,Cin), dy (B,H,W,Cout) on the same grid, part[nsplit][9][Cout][Cin]. insar_wgrad_conv3_tile returns
- * (tile(Cin) << 16) | tile(Cout) (tiles <= 128), or 0 when the layer needs insar_wgrad (not bf16; W neither a
- * multiple of 64 nor 16 / 32). */
+ * (tile(Cin) << 16) | tile(Cout) (tiles <= 128), or 0 when the layer needs insar_wgrad (W neither a multiple of 64
+ * nor 16 / 32). */
 int insar_wgrad_conv3_tile(const InsarAct* x, int32_t Cout);
 int insar_wgrad_conv3(const InsarAct* x, const InsarAct* dy, float* part, int32_t nsplit, void* stream);
 /* grad = sum_split part[...] re-laid out to the torch parameter layout.

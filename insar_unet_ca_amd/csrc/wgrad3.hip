@@ -37,9 +37,9 @@ __device__ __forceinline__ int w3_swz(int row) {
   else return ((row >> 1) & 3) << 1;
 }
 
-template <int TM, int TN, int NW>
+template <typename T, int TM, int TN, int NW>
 struct Wgrad3Cfg {
-  static constexpr int ES = 2;
+  static constexpr int ES = sizeof(T);
   static constexpr int THREADS = NW * 64;
   static constexpr int SUBX = (TM * ES > 256) ? TM * ES / 256 : 1, SUBY = (TN * ES > 256) ? TN * ES / 256 : 1;
   static constexpr int RBX = TM * ES / SUBX, RBY = TN * ES / SUBY;
@@ -54,10 +54,10 @@ struct Wgrad3Cfg {
   static_assert(YCHUNKS % THREADS == 0, "dY stage must be whole block-wide DMA instructions");
 };
 
-template <int TM, int TN, int NW>
+template <typename T, int TM, int TN, int NW>
 __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad3_kernel(Wgrad3Args a) {
-  using Cfg = Wgrad3Cfg<TM, TN, NW>;
-  constexpr int THREADS = Cfg::THREADS, ES = 2;
+  using Cfg = Wgrad3Cfg<T, TM, TN, NW>;
+  constexpr int THREADS = Cfg::THREADS, ES = Cfg::ES;
   constexpr int MTW = Cfg::MTW, NTW = Cfg::NTW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -151,48 +151,81 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad3_kernel(Wgra
       if (ks + 1 < ks1) stage(buf ^ 1, next_pixel());
       const char* sX = smem + buf * Cfg::STAGE;
       const char* sY = sX + Cfg::X_STAGE;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8_t yf[NTW];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int sel = h ^ (kq & 1);
-          const int row = s * 32 + kq * 8 + sel * 4 + (r16 >> 2);
-#pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) {
-            const int colw = (wn * (NTW * 16) + nt * 16 + (r16 & 3) * 4) * 2;
-            int sub = 0, colb = colw;
-            if constexpr (Cfg::SUBY > 1) { sub = colw / Cfg::RBY; colb = colw % Cfg::RBY; }
-            const int pc = (colb >> 4) ^ w3_swz<Cfg::RBY>(row);
-            const char* p = sY + sub * (W3_BKP * Cfg::RBY) + row * Cfg::RBY + pc * 16 + (colb & 15);
-            s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
-            yf[nt][4 * h + 0] = v[0]; yf[nt][4 * h + 1] = v[1]; yf[nt][4 * h + 2] = v[2]; yf[nt][4 * h + 3] = v[3];
-          }
-        }
-#pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3) {
-          bf16x8_t xf[MTW];
-#pragma unroll
+      if constexpr (ES == 2) {
+  #pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bf16x8_t yf[NTW];
+  #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const int sel = h ^ (kq & 1);
-            const int k = s * 32 + kq * 8 + sel * 4 + (r16 >> 2);
-            const int row = k + 2 * (k >> a.lw) + t3;                         // X rows lead the dY rows by one pixel
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) {
-              const int colw = (wm * (TM / 2) + mt * 16 + (r16 & 3) * 4) * 2;
+            const int row = s * 32 + kq * 8 + sel * 4 + (r16 >> 2);
+  #pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+              const int colw = (wn * (NTW * 16) + nt * 16 + (r16 & 3) * 4) * 2;
               int sub = 0, colb = colw;
-              if constexpr (Cfg::SUBX > 1) { sub = colw / Cfg::RBX; colb = colw % Cfg::RBX; }
-              const int pc = (colb >> 4) ^ w3_swz<Cfg::RBX>(row);
-              const char* p = sX + sub * (W3_XR * Cfg::RBX) + row * Cfg::RBX + pc * 16 + (colb & 15);
+              if constexpr (Cfg::SUBY > 1) { sub = colw / Cfg::RBY; colb = colw % Cfg::RBY; }
+              const int pc = (colb >> 4) ^ w3_swz<Cfg::RBY>(row);
+              const char* p = sY + sub * (W3_BKP * Cfg::RBY) + row * Cfg::RBY + pc * 16 + (colb & 15);
               s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
-              xf[mt][4 * h + 0] = v[0]; xf[mt][4 * h + 1] = v[1]; xf[mt][4 * h + 2] = v[2]; xf[mt][4 * h + 3] = v[3];
+              yf[nt][4 * h + 0] = v[0]; yf[nt][4 * h + 1] = v[1]; yf[nt][4 * h + 2] = v[2]; yf[nt][4 * h + 3] = v[3];
             }
           }
+  #pragma unroll
+          for (int t3 = 0; t3 < 3; ++t3) {
+            bf16x8_t xf[MTW];
+  #pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int sel = h ^ (kq & 1);
+              const int k = s * 32 + kq * 8 + sel * 4 + (r16 >> 2);
+              const int row = k + 2 * (k >> a.lw) + t3;                         // X rows lead the dY rows by one pixel
+  #pragma unroll
+              for (int mt = 0; mt < MTW; ++mt) {
+                const int colw = (wm * (TM / 2) + mt * 16 + (r16 & 3) * 4) * 2;
+                int sub = 0, colb = colw;
+                if constexpr (Cfg::SUBX > 1) { sub = colw / Cfg::RBX; colb = colw % Cfg::RBX; }
+                const int pc = (colb >> 4) ^ w3_swz<Cfg::RBX>(row);
+                const char* p = sX + sub * (W3_XR * Cfg::RBX) + row * Cfg::RBX + pc * 16 + (colb & 15);
+                s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+                xf[mt][4 * h + 0] = v[0]; xf[mt][4 * h + 1] = v[1]; xf[mt][4 * h + 2] = v[2]; xf[mt][4 * h + 3] = v[3];
+              }
+            }
+  #pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+  #pragma unroll
+              for (int nt = 0; nt < NTW; ++nt)
+                acc[t3][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[mt], yf[nt], acc[t3][mt][nt], 0, 0, 0);
+          }
+        }
+      } else {
+        // fp32: v_mfma_f32_16x16x4_f32, one pixel row per lane group (kq) and step
+#pragma unroll 4
+        for (int jj = 0; jj < W3_BKP / 4; ++jj) {
+          const int k = jj * 4 + kq;
+          float yf[NTW];
 #pragma unroll
-          for (int mt = 0; mt < MTW; ++mt)
+          for (int nt = 0; nt < NTW; ++nt) {
+            const int colw = (wn * (NTW * 16) + nt * 16 + r16) * 4;
+            const int sub = colw / Cfg::RBY, colb = colw % Cfg::RBY;
+            const int pc = (colb >> 4) ^ w3_swz<Cfg::RBY>(k);
+            yf[nt] = *(const float*)(sY + sub * (W3_BKP * Cfg::RBY) + k * Cfg::RBY + pc * 16 + (colb & 15));
+          }
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-              acc[t3][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[mt], yf[nt], acc[t3][mt][nt], 0, 0, 0);
+          for (int t3 = 0; t3 < 3; ++t3) {
+            const int row = k + 2 * (k >> a.lw) + t3;
+            float xf[MTW];
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+              const int colw = (wm * (TM / 2) + mt * 16 + r16) * 4;
+              const int sub = colw / Cfg::RBX, colb = colw % Cfg::RBX;
+              const int pc = (colb >> 4) ^ w3_swz<Cfg::RBX>(row);
+              xf[mt] = *(const float*)(sX + sub * (W3_XR * Cfg::RBX) + row * Cfg::RBX + pc * 16 + (colb & 15));
+            }
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < NTW; ++nt)
+                acc[t3][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[mt], yf[nt], acc[t3][mt][nt], 0, 0, 0);
+          }
         }
       }
       dma_drain_and_barrier();
@@ -214,27 +247,28 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad3_kernel(Wgra
   }
 }
 
-template <int TM, int TN, int NW>
+template <typename T, int TM, int TN, int NW>
 static int launch_wgrad3(Wgrad3Args& a, hipStream_t s) {
-  using Cfg = Wgrad3Cfg<TM, TN, NW>;
+  using Cfg = Wgrad3Cfg<T, TM, TN, NW>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad3_kernel<TM, TN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad3_kernel<T, TM, TN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_wgrad_conv3: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
   a.mtc = a.Cin / TM; a.ntc = a.Cout / TN;
   const long long grid = (long long)a.nsplit * 3 * a.mtc * a.ntc;
   if (grid > 0x7fffffffLL) INSAR_FAIL(INSAR_E_SHAPE, "insar_wgrad_conv3: grid too large");
-  hipLaunchKernelGGL((wgrad3_kernel<TM, TN, NW>), dim3((unsigned)grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((wgrad3_kernel<T, TM, TN, NW>), dim3((unsigned)grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, a);
   INSAR_CHECK_LAUNCH("insar_wgrad_conv3");
   return INSAR_OK;
 }
 
 // (tile(Cin) << 16) | tile(Cout) of the row-of-taps kernel for this layer, or 0 when the per-tap kernel (insar_wgrad)
-// has to be used: bf16, image rows that are whole K steps, and a tile whose three accumulator sets fit the registers.
+// has to be used: image rows that are whole K steps (or K steps that are whole image rows), and a tile whose three
+// accumulator sets fit the registers.
 extern "C" int insar_wgrad_conv3_tile(const InsarAct* x, int32_t Cout) {
-  if (!x || x->dtype != INSAR_BF16 || x->c_len % 64 || Cout % 64) return 0;
+  if (!x || x->c_len % 64 || Cout % 64) return 0;
   const bool rows_ok = (x->W % W3_BKP) == 0 || ((x->W == 16 || x->W == 32) && (x->H % (W3_BKP / x->W)) == 0);
   if (!rows_ok) return 0;
   const int pair = insar_wgrad_tile_pair(x->c_len, Cout, x->dtype);
@@ -256,7 +290,7 @@ extern "C" int insar_wgrad_conv3(const InsarAct* x, const InsarAct* dy, float* p
   if (x->B != dy->B || x->H != dy->H || x->W != dy->W) INSAR_FAIL(INSAR_E_SHAPE, "insar_wgrad_conv3: x/dy grids differ");
   if (x->dtype != dy->dtype) INSAR_FAIL(INSAR_E_DTYPE, "insar_wgrad_conv3: x/dy dtype differ");
   const int pair = insar_wgrad_conv3_tile(x, dy->c_len);
-  if (!pair) INSAR_FAIL(INSAR_E_SHAPE, "insar_wgrad_conv3: unsupported layer (bf16; W %% 64 == 0, or W = 16 / 32 with whole K steps per image); use insar_wgrad");
+  if (!pair) INSAR_FAIL(INSAR_E_SHAPE, "insar_wgrad_conv3: unsupported layer (W %% 64 == 0, or W = 16 / 32 with whole K steps per image); use insar_wgrad");
   if (nsplit < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_wgrad_conv3: nsplit");
   Wgrad3Args a;
   a.x = (const char*)x->ptr; a.dy = (const char*)dy->ptr; a.part = part;
@@ -271,8 +305,12 @@ extern "C" int insar_wgrad_conv3(const InsarAct* x, const InsarAct* dy, float* p
   a.Cdy = dy->C; a.cdy_off = dy->c_off; a.Cout = dy->c_len;
   hipStream_t s = (hipStream_t)stream;
   const int tm = pair >> 16, tn = pair & 0xffff;
-  if (tm == 128 && tn == 128) return launch_wgrad3<128, 128, 8>(a, s);
-  if (tm == 128) return launch_wgrad3<128, 64, 4>(a, s);
-  if (tn == 128) return launch_wgrad3<64, 128, 4>(a, s);
-  return launch_wgrad3<64, 64, 4>(a, s);
+  if (x->dtype != INSAR_BF16) {          // fp32: 128 x 128 (8 waves) or 64 x 64, as insar_wgrad_tile_pair says
+    if (tm == 128 && tn == 128) return launch_wgrad3<float, 128, 128, 8>(a, s);
+    return launch_wgrad3<float, 64, 64, 4>(a, s);
+  }
+  if (tm == 128 && tn == 128) return launch_wgrad3<bf16_t, 128, 128, 8>(a, s);
+  if (tm == 128) return launch_wgrad3<bf16_t, 128, 64, 4>(a, s);
+  if (tn == 128) return launch_wgrad3<bf16_t, 64, 128, 4>(a, s);
+  return launch_wgrad3<bf16_t, 64, 64, 4>(a, s);
 }

@@ -544,7 +544,8 @@ def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
         nsplit = _wgrad_nsplit(tiles, B * H * W // WG_BKP, 9 * cout * cin, tm, tn, ctx.esize, taps_per_wg=3)
         part = ctx.wgrad_part(nsplit * 9 * cout * cin)
         if PROFILER is not None:
-            tag = "wgrad3_kernel<%d, %d, %d>" % (tm, tn, 8 if tm == 128 and tn == 128 else 4)
+            tag = "wgrad3_kernel<%s, %d, %d, %d>" % ("float" if ctx.code == _lib.F32 else "bf16_t", tm, tn,
+                                                     8 if tm == 128 and tn == 128 else 4)
             # algorithmic bytes: both operands read once, the split-K slabs written once
             nbytes = ctx.esize * B * H * W * (cin + cout) + 4.0 * nsplit * 9 * cout * cin
             PROFILER.run(tag, 2.0 * B * H * W * cin * cout * 9,
