@@ -26,5 +26,7 @@ cp $(ls "$OUT"/pF/*/*_counter_collection.csv | head -n 1) "$OUT/pmc_fetch.csv"
 cp $(ls "$OUT"/pW/*/*_counter_collection.csv | head -n 1) "$OUT/pmc_write.csv"
 python3 "$R/tools/pmc_traffic.py" "$OUT/pmc_fetch.csv" "$OUT/pmc_write.csv" "$OUT/pmc_traffic.json"
 rm -rf "$OUT/p1" "$OUT/p2" "$OUT/pF" "$OUT/pW"      # keep the summaries only (the traces are large)
+echo "== 2-rank rehearsal (gloo, both ranks on the one GPU: exercises the bucketed reducer inside backward)"
+timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 "$R/bench.py" --gpus 2 --steps 3 --warmup 1 --backend gloo --no-cpu-baseline --no-kernel-timing > "$OUT/bench_dp2_gloo.json" 2> "$OUT/bench_dp2_gloo.err"; cut -c1-160 "$OUT/bench_dp2_gloo.json"
 echo "== config 4"; timeout -k 10 300 python3 "$R/bench.py" --dtype f32 --size 512 --batch 8 --loss ce --no-cpu-baseline > "$OUT/bench_cfg4.json" 2> "$OUT/bench_cfg4.err"; cut -c1-200 "$OUT/bench_cfg4.json"
 echo done
