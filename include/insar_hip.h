@@ -276,6 +276,21 @@ int insar_bnrelu_bwd_apply_part(const InsarAct* dout, const InsarAct* y, const f
                                 const float* mean, const float* invstd, const float* gate, const float* coefB,
                                 const float* tb, const float* tg, const InsarAct* dy, int32_t relu, void* stream);
 
+/* ---- the unit that feeds the 1x1 output conv (outc, Unet-ChannalAttention.py:125,162) ----------------------------
+ * Its incoming gradient is g[n,h,w,c] = round_T(sum_k dlogits[n,k,h,w] * W[k][c]): 2K multiply-adds per element, so the
+ * reduce and apply passes recompute it from dlogits (fp32 [B][K][H][W], K <= 4) and outc's weight ([K][C] fp32)
+ * instead of reading a materialised 64-channel tensor, and insar_conv1x1_out_wgrad produces outc's parameter
+ * gradients (part as insar_conv1x1_out_bwd) without writing that tensor. Bitwise the same results as
+ * insar_conv1x1_out_bwd + insar_bnrelu_bwd_reduce + insar_bnrelu_bwd_apply, three activation-sized HBM passes less. */
+int insar_conv1x1_out_wgrad(const InsarAct* x, const float* w, const float* dlogits, int32_t K, float* part, void* stream);
+int insar_bnrelu_bwd_reduce_outc(const float* dlogits, const float* wout, int32_t K, const InsarAct* y,
+                                 const float* scale, const float* shift, float* part, int32_t relu,
+                                 int32_t rows_per_part, void* stream);
+int insar_bnrelu_bwd_apply_outc(const float* dlogits, const float* wout, int32_t K, const InsarAct* y,
+                                const float* scale, const float* shift, const float* mean, const float* invstd,
+                                const float* gate, const float* coefB, const float* k1, const float* k2,
+                                const InsarAct* dy, int32_t relu, void* stream);
+
 /* ---- ChannelAttentionModule (DeepLabV3-ChannelAttention.py:49-79; config 5) ---------------------------
  * out = x * sigmoid(W2 relu(W1 avg_hw(x)) + W2 relu(W1 max_hw(x))), W1 (Cr,C), W2 (C,Cr), no biases.
  * forward : insar_cam_pool -> insar_cam_excite -> insar_bn_relu_apply(x, ones, zeros, gate, out, relu=0)

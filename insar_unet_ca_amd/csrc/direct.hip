@@ -505,7 +505,7 @@ __global__ void conv1x1_out_bwd_kernel(ActView x, const float* __restrict__ wt, 
           if (cc == 0) ab[k] += g;
         }
       }
-      *(uint4*)(dx.base + (dx.elem_offset(n, h, w) + (int64_t)cc * CH) * (int64_t)sizeof(T)) = Chunk<T>::pack(o);
+      if (dx.base) *(uint4*)(dx.base + (dx.elem_offset(n, h, w) + (int64_t)cc * CH) * (int64_t)sizeof(T)) = Chunk<T>::pack(o);
     }
   }
   const int pw = K * C + K;
@@ -569,5 +569,22 @@ extern "C" int insar_conv1x1_out_bwd(const InsarAct* x, const float* w, const fl
   if (x->dtype == INSAR_BF16) hipLaunchKernelGGL(conv1x1_out_bwd_kernel<bf16_t>, dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), w, dlogits, K, make_view(*dx), part);
   else hipLaunchKernelGGL(conv1x1_out_bwd_kernel<float>, dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), w, dlogits, K, make_view(*dx), part);
   INSAR_CHECK_LAUNCH("insar_conv1x1_out_bwd");
+  return INSAR_OK;
+}
+
+// Parameter gradients only (part as above), for callers that recompute the input gradient where it is consumed
+// (insar_bnrelu_bwd_reduce_outc / insar_bnrelu_bwd_apply_outc): no 64-channel gradient tensor is written.
+extern "C" int insar_conv1x1_out_wgrad(const InsarAct* x, const float* w, const float* dlogits, int32_t K, float* part,
+                                       void* stream) {
+  int rc;
+  if ((rc = check_out(x, K, "insar_conv1x1_out_wgrad"))) return rc;
+  if (!w || !dlogits || !part) INSAR_FAIL(INSAR_E_ARG, "insar_conv1x1_out_wgrad: null pointer");
+  size_t lds = (size_t)(K * x->c_len + 4 * (K * x->c_len + K)) * sizeof(float);
+  int grid = insar_conv1x1_out_bwd_blocks(x->B, x->H);
+  hipStream_t s = (hipStream_t)stream;
+  ActView none = make_view(*x); none.base = nullptr;
+  if (x->dtype == INSAR_BF16) hipLaunchKernelGGL(conv1x1_out_bwd_kernel<bf16_t>, dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), w, dlogits, K, none, part);
+  else hipLaunchKernelGGL(conv1x1_out_bwd_kernel<float>, dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), w, dlogits, K, none, part);
+  INSAR_CHECK_LAUNCH("insar_conv1x1_out_wgrad");
   return INSAR_OK;
 }

@@ -583,14 +583,46 @@ extern "C" int insar_bn_relu_apply_pool(const InsarAct* y, const float* scale, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// "Virtual" gradient of the 1x1 output conv (outc, Unet-ChannalAttention.py:125,162): the gradient wrt outc's input,
+//   g[n,h,w,c] = round_T( sum_k dlogits[n,k,h,w] * W[k][c] )        (k ascending, fma chain, as conv1x1_out_bwd stores it)
+// costs 2K multiply-adds per element, so the BatchNorm-backward reduce and apply passes of the unit that feeds outc
+// recompute it from the K-channel fp32 dlogits instead of reading a materialised 64-channel tensor twice (and
+// conv1x1_out_bwd does not write it): 3 activation-sized HBM passes less per step, bitwise the same numbers.
+// ---------------------------------------------------------------------------------------------
+#define OG_MAXK 4
+struct OutcGrad {
+  const float* dl;      // [B][K][H][W] fp32, or null: read the gradient tensor
+  const float* w;       // [K][C] fp32
+  int K;
+};
+template <typename T, int KM>
+__device__ __forceinline__ void outc_grad_chunk(const float (&dlv)[KM], const float (&wk)[KM][Chunk<T>::N], int K,
+                                                float (&gg)[Chunk<T>::N]) {
+  constexpr int CH = Chunk<T>::N;
+  float o[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) o[j] = 0.f;
+#pragma unroll
+  for (int k = 0; k < KM; ++k)
+    if (k < K) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) o[j] = fmaf(dlv[k], wk[k][j], o[j]);
+    }
+  Chunk<T>::unpack(Chunk<T>::pack(o), gg);          // the rounding a stored gradient tensor would have had
+}
+
+// ---------------------------------------------------------------------------------------------
 // Row reductions. Both produce part[(n*H + h)][2][C] per-row partial sums over w:
 //   se_squeeze      : q0 = mask,          q1 = mask * y          (mask = y*scale+shift > 0)
 //   bnrelu_bwd_reduce: q0 = dout * mask,  q1 = dout * mask * y
 // Cross-thread reduction through LDS (threads that own the same channel chunk).
 // ---------------------------------------------------------------------------------------------
-template <typename T, bool WITH_G>
-__global__ void row_reduce_kernel(ActView g, ActView y, const float* __restrict__ scale,
-                                  const float* __restrict__ shift, float* __restrict__ part, int relu, int rpp) {
+// VK = 0: dout read from memory; VK = 2 / 4: dout recomputed from dlogits with K <= VK classes (own instantiations with
+// their own register budget: the plain passes keep theirs)
+template <typename T, bool WITH_G, int VK = 0>
+__global__ void __launch_bounds__(VK ? 512 : 1024) row_reduce_kernel(ActView g, ActView y, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, float* __restrict__ part, int relu, int rpp,
+                                  OutcGrad og) {
   constexpr int CH = Chunk<T>::N;
   __shared__ float red[PW_THREADS][2 * CH + 1];
   const int cpp = y.c_len / CH;
@@ -605,22 +637,40 @@ __global__ void row_reduce_kernel(ActView g, ActView y, const float* __restrict_
       const int cc = threadIdx.x % cpp;
 #pragma unroll
       for (int j = 0; j < CH; ++j) { a0[j] = 0.f; a1[j] = 0.f; sc[j] = scale[cc * CH + j]; sh[j] = shift[cc * CH + j]; }
+      constexpr bool virt = WITH_G && VK > 0;
+      constexpr int KM = virt ? VK : 1;
+      float wk[KM][CH];
+      if constexpr (virt) {
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+#pragma unroll
+          for (int j = 0; j < CH; ++j) wk[k][j] = k < og.K ? og.w[k * y.c_len + cc * CH + j] : 0.f;
+      }
+      const int64_t HW = (int64_t)y.H * y.W;
       const int wstep = blockDim.x / cpp;
       for (int h = h0; h < h1; ++h) {
         for (int w0 = threadIdx.x / cpp; w0 < y.W; w0 += PW_UNROLL * wstep) {
           uint4 vy[PW_UNROLL], vg[PW_UNROLL];
+          float dlv[PW_UNROLL][KM];
 #pragma unroll
           for (int u = 0; u < PW_UNROLL; ++u)
             if (w0 + u * wstep < y.W) {
               vy[u] = *chunk_ptr<T>(y, n, h, w0 + u * wstep, cc);
-              if constexpr (WITH_G) vg[u] = *chunk_ptr<T>(g, n, h, w0 + u * wstep, cc);
+              if constexpr (virt) {
+#pragma unroll
+                for (int k = 0; k < KM; ++k)
+                  if (k < og.K) dlv[u][k] = og.dl[((int64_t)n * og.K + k) * HW + (int64_t)h * y.W + w0 + u * wstep];
+              } else if constexpr (WITH_G) {
+                vg[u] = *chunk_ptr<T>(g, n, h, w0 + u * wstep, cc);
+              }
             }
 #pragma unroll
           for (int u = 0; u < PW_UNROLL; ++u)
             if (w0 + u * wstep < y.W) {
               float f[CH], gg[CH];
               Chunk<T>::unpack(vy[u], f);
-              if constexpr (WITH_G) Chunk<T>::unpack(vg[u], gg);
+              if constexpr (virt) outc_grad_chunk<T, KM>(dlv[u], wk, og.K, gg);
+              else if constexpr (WITH_G) Chunk<T>::unpack(vg[u], gg);
 #pragma unroll
               for (int j = 0; j < CH; ++j) {
                 const bool on = !relu || fmaf(f[j], sc[j], sh[j]) > 0.f;
@@ -676,27 +726,64 @@ extern "C" int insar_se_squeeze(const InsarAct* y, const float* scale, const flo
   int grid = insar_grid_cap((int64_t)y->B * ((y->H + rpp - 1) / rpp));
   hipStream_t s = (hipStream_t)stream;
   ActView v = make_view(*y);
-  if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, false>), dim3(grid), dim3(PW_THREADS), 0, s, v, v, scale, shift, part, relu, rpp);
-  else hipLaunchKernelGGL((row_reduce_kernel<float, false>), dim3(grid), dim3(PW_THREADS), 0, s, v, v, scale, shift, part, relu, rpp);
+  if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, false>), dim3(grid), dim3(PW_THREADS), 0, s, v, v, scale, shift, part, relu, rpp, OutcGrad{nullptr, nullptr, 0});
+  else hipLaunchKernelGGL((row_reduce_kernel<float, false>), dim3(grid), dim3(PW_THREADS), 0, s, v, v, scale, shift, part, relu, rpp, OutcGrad{nullptr, nullptr, 0});
   INSAR_CHECK_LAUNCH("insar_se_squeeze");
+  return INSAR_OK;
+}
+
+static int check_outc_grad(const InsarAct* y, const float* dlogits, const float* wout, int32_t K, const char* who) {
+  if (!dlogits || !wout) INSAR_FAIL(INSAR_E_ARG, "%s: null dlogits / weight", who);
+  if (K < 1 || K > OG_MAXK) INSAR_FAIL(INSAR_E_SHAPE, "%s: num_classes=%d must be 1..%d", who, K, OG_MAXK);
+  const int ch = y->dtype == INSAR_BF16 ? 8 : 4;
+  if (y->c_len % ch || PW_THREADS % (y->c_len / ch)) INSAR_FAIL(INSAR_E_SHAPE, "%s: C=%d unsupported", who, y->c_len);
+  return INSAR_OK;
+}
+
+static int launch_bwd_reduce(const char* who, const InsarAct* dout, const InsarAct* y, const float* scale, const float* shift,
+                             float* part, int32_t relu, int32_t rows_per_part, OutcGrad og, void* stream) {
+  int rc;
+  if ((rc = insar_check_act(y, who, "y"))) return rc;
+  if (!og.dl) {
+    if ((rc = insar_check_act(dout, who, "dout"))) return rc;
+    if ((rc = check_same_grid(y, dout, who))) return rc;
+  }
+  if (!scale || !shift || !part) INSAR_FAIL(INSAR_E_ARG, "%s: null pointer", who);
+  if (rows_per_part < 1) INSAR_FAIL(INSAR_E_SHAPE, "%s: rows_per_part", who);
+  const int rpp = rows_per_part;
+  int grid = insar_grid_cap((int64_t)y->B * ((y->H + rpp - 1) / rpp));
+  hipStream_t s = (hipStream_t)stream;
+  const ActView vy = make_view(*y), vg = og.dl ? vy : make_view(*dout);
+  if (og.dl && og.K <= 2) {
+    if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, true, 2>), dim3(grid), dim3(PW_THREADS), 0, s, vg, vy, scale, shift, part, relu, rpp, og);
+    else hipLaunchKernelGGL((row_reduce_kernel<float, true, 2>), dim3(grid), dim3(PW_THREADS), 0, s, vg, vy, scale, shift, part, relu, rpp, og);
+  } else if (og.dl) {
+    if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, true, OG_MAXK>), dim3(grid), dim3(PW_THREADS), 0, s, vg, vy, scale, shift, part, relu, rpp, og);
+    else hipLaunchKernelGGL((row_reduce_kernel<float, true, OG_MAXK>), dim3(grid), dim3(PW_THREADS), 0, s, vg, vy, scale, shift, part, relu, rpp, og);
+  } else {
+    if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, true>), dim3(grid), dim3(PW_THREADS), 0, s, vg, vy, scale, shift, part, relu, rpp, og);
+    else hipLaunchKernelGGL((row_reduce_kernel<float, true>), dim3(grid), dim3(PW_THREADS), 0, s, vg, vy, scale, shift, part, relu, rpp, og);
+  }
+  INSAR_CHECK_LAUNCH(who);
   return INSAR_OK;
 }
 
 extern "C" int insar_bnrelu_bwd_reduce(const InsarAct* dout, const InsarAct* y, const float* scale, const float* shift,
                                        float* part, int32_t relu, int32_t rows_per_part, void* stream) {
+  return launch_bwd_reduce("insar_bnrelu_bwd_reduce", dout, y, scale, shift, part, relu, rows_per_part,
+                           OutcGrad{nullptr, nullptr, 0}, stream);
+}
+
+// The same sums with dout = gradient of the 1x1 output conv's input, recomputed from dlogits [B][K][H][W] (fp32) and
+// the conv's weight [K][C] instead of read from memory (see OutcGrad above).
+extern "C" int insar_bnrelu_bwd_reduce_outc(const float* dlogits, const float* wout, int32_t K, const InsarAct* y,
+                                            const float* scale, const float* shift, float* part, int32_t relu,
+                                            int32_t rows_per_part, void* stream) {
   int rc;
-  if ((rc = insar_check_act(y, "insar_bnrelu_bwd_reduce", "y"))) return rc;
-  if ((rc = insar_check_act(dout, "insar_bnrelu_bwd_reduce", "dout"))) return rc;
-  if ((rc = check_same_grid(y, dout, "insar_bnrelu_bwd_reduce"))) return rc;
-  if (!scale || !shift || !part) INSAR_FAIL(INSAR_E_ARG, "insar_bnrelu_bwd_reduce: null pointer");
-  if (rows_per_part < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_bnrelu_bwd_reduce: rows_per_part");
-  const int rpp = rows_per_part;
-  int grid = insar_grid_cap((int64_t)y->B * ((y->H + rpp - 1) / rpp));
-  hipStream_t s = (hipStream_t)stream;
-  if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, true>), dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, part, relu, rpp);
-  else hipLaunchKernelGGL((row_reduce_kernel<float, true>), dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, part, relu, rpp);
-  INSAR_CHECK_LAUNCH("insar_bnrelu_bwd_reduce");
-  return INSAR_OK;
+  if ((rc = insar_check_act(y, "insar_bnrelu_bwd_reduce_outc", "y"))) return rc;
+  if ((rc = check_outc_grad(y, dlogits, wout, K, "insar_bnrelu_bwd_reduce_outc"))) return rc;
+  return launch_bwd_reduce("insar_bnrelu_bwd_reduce_outc", nullptr, y, scale, shift, part, relu, rows_per_part,
+                           OutcGrad{dlogits, wout, K}, stream);
 }
 
 // Sum `rows` rows of a [rows][cols] fp32 slab into out[cols] (LDS), all threads of the block cooperating:
@@ -969,13 +1056,13 @@ extern "C" int insar_bnse_bwd_coef_stage(const InsarBnSeBwd* d, const float* red
 
 // dy = scale * ( (dout*gate + coefB) * mask - k1 - xhat*k2 ),  xhat = (y - mean)*invstd
 #define BWD_APPLY_MAXC 1024
-template <typename T>
-__global__ void bnrelu_bwd_apply_kernel(ActView g, ActView y, const float* __restrict__ scale,
+template <typename T, int VK = 0>       // VK as in row_reduce_kernel
+__global__ void __launch_bounds__(VK ? 512 : 1024) bnrelu_bwd_apply_kernel(ActView g, ActView y, const float* __restrict__ scale,
                                         const float* __restrict__ shift, const float* __restrict__ mean,
                                         const float* __restrict__ invstd, const float* __restrict__ gate,
                                         const float* __restrict__ coefB, const float* k1,
                                         const float* k2, ActView dy, int relu,
-                                        const float* __restrict__ tb, const float* __restrict__ tg) {
+                                        const float* __restrict__ tb, const float* __restrict__ tg, OutcGrad og) {
   constexpr int CH = Chunk<T>::N;
   const int cpp = y.c_len / CH;
   const int rows = y.B * y.H;
@@ -1004,6 +1091,16 @@ __global__ void bnrelu_bwd_apply_kernel(ActView g, ActView y, const float* __res
       sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c]; c1[j] = k1[c]; c2[j] = k2[c];
       ga[j] = 1.f; cb[j] = 0.f;
     }
+    constexpr bool virt = VK > 0;                     // dout recomputed from dlogits (see OutcGrad): own instantiation
+    constexpr int KM = virt ? VK : 1;
+    float wk[KM][CH];
+    if constexpr (virt) {
+#pragma unroll
+      for (int k = 0; k < KM; ++k)
+#pragma unroll
+        for (int j = 0; j < CH; ++j) wk[k][j] = k < og.K ? og.w[k * y.c_len + cc * CH + j] : 0.f;
+    }
+    const int64_t HW = (int64_t)y.H * y.W;
     int n_loaded = -1;
     for (int r = blockIdx.x; r < rows; r += gridDim.x) {
       const int n = r / y.H, h = r - n * y.H;
@@ -1017,18 +1114,26 @@ __global__ void bnrelu_bwd_apply_kernel(ActView g, ActView y, const float* __res
       }
       for (int w0 = threadIdx.x / cpp; w0 < y.W; w0 += PW_UNROLL * wstep) {
         uint4 vy[PW_UNROLL], vg[PW_UNROLL];
+        float dlv[PW_UNROLL][KM];
 #pragma unroll
         for (int u = 0; u < PW_UNROLL; ++u)
           if (w0 + u * wstep < y.W) {
             vy[u] = *chunk_ptr<T>(y, n, h, w0 + u * wstep, cc);
-            vg[u] = *chunk_ptr<T>(g, n, h, w0 + u * wstep, cc);
+            if constexpr (virt) {
+#pragma unroll
+              for (int k = 0; k < KM; ++k)
+                if (k < og.K) dlv[u][k] = og.dl[((int64_t)n * og.K + k) * HW + (int64_t)h * y.W + w0 + u * wstep];
+            } else {
+              vg[u] = *chunk_ptr<T>(g, n, h, w0 + u * wstep, cc);
+            }
           }
 #pragma unroll
         for (int u = 0; u < PW_UNROLL; ++u)
           if (w0 + u * wstep < y.W) {
             float f[CH], gg[CH], o[CH];
             Chunk<T>::unpack(vy[u], f);
-            Chunk<T>::unpack(vg[u], gg);
+            if constexpr (virt) outc_grad_chunk<T, KM>(dlv[u], wk, og.K, gg);
+            else Chunk<T>::unpack(vg[u], gg);
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
               const bool on = !relu || fmaf(f[j], sc[j], sh[j]) > 0.f;
@@ -1071,12 +1176,14 @@ __global__ void bnrelu_bwd_apply_kernel(ActView g, ActView y, const float* __res
 static int launch_bwd_apply(const char* who, const InsarAct* dout, const InsarAct* y, const float* scale, const float* shift,
                             const float* mean, const float* invstd, const float* gate, const float* coefB,
                             const float* k1, const float* k2, const InsarAct* dy, int32_t relu,
-                            const float* tb, const float* tg, void* stream) {
+                            const float* tb, const float* tg, OutcGrad og, void* stream) {
   int rc;
   if ((rc = insar_check_act(y, who, "y"))) return rc;
-  if ((rc = insar_check_act(dout, who, "dout"))) return rc;
+  if (!og.dl) {
+    if ((rc = insar_check_act(dout, who, "dout"))) return rc;
+    if ((rc = check_same_grid(y, dout, who))) return rc;
+  }
   if ((rc = insar_check_act(dy, who, "dy"))) return rc;
-  if ((rc = check_same_grid(y, dout, who))) return rc;
   if ((rc = check_same_grid(y, dy, who))) return rc;
   if (!scale || !shift || !mean || !invstd) INSAR_FAIL(INSAR_E_ARG, "%s: null pointer", who);
   if (!tb && (!k1 || !k2)) INSAR_FAIL(INSAR_E_ARG, "%s: null k1/k2", who);
@@ -1084,10 +1191,15 @@ static int launch_bwd_apply(const char* who, const InsarAct* dout, const InsarAc
     INSAR_FAIL(INSAR_E_SHAPE, "%s: partial sums need tg and C <= %d", who, BWD_APPLY_MAXC);
   int grid = insar_grid_cap((int64_t)y->B * y->H);
   hipStream_t s = (hipStream_t)stream;
-  if (y->dtype == INSAR_BF16)
-    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, mean, invstd, gate, coefB, k1, k2, make_view(*dy), relu, tb, tg);
+#define LAUNCH_APPLY_VK(TT, VKK) hipLaunchKernelGGL((bnrelu_bwd_apply_kernel<TT, VKK>), dim3(grid), dim3(PW_THREADS), 0, s, make_view(*y), make_view(*y), scale, shift, mean, invstd, gate, coefB, k1, k2, make_view(*dy), relu, tb, tg, og)
+  if (og.dl) {
+    if (y->dtype == INSAR_BF16) { if (og.K <= 2) LAUNCH_APPLY_VK(bf16_t, 2); else LAUNCH_APPLY_VK(bf16_t, OG_MAXK); }
+    else { if (og.K <= 2) LAUNCH_APPLY_VK(float, 2); else LAUNCH_APPLY_VK(float, OG_MAXK); }
+#undef LAUNCH_APPLY_VK
+  } else if (y->dtype == INSAR_BF16)
+    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, mean, invstd, gate, coefB, k1, k2, make_view(*dy), relu, tb, tg, og);
   else
-    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel<float>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, mean, invstd, gate, coefB, k1, k2, make_view(*dy), relu, tb, tg);
+    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel<float>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, mean, invstd, gate, coefB, k1, k2, make_view(*dy), relu, tb, tg, og);
   INSAR_CHECK_LAUNCH(who);
   return INSAR_OK;
 }
@@ -1096,7 +1208,19 @@ extern "C" int insar_bnrelu_bwd_apply(const InsarAct* dout, const InsarAct* y, c
                                       const float* mean, const float* invstd, const float* gate, const float* coefB,
                                       const float* k1, const float* k2, const InsarAct* dy, int32_t relu, void* stream) {
   return launch_bwd_apply("insar_bnrelu_bwd_apply", dout, y, scale, shift, mean, invstd, gate, coefB, k1, k2, dy, relu,
-                          nullptr, nullptr, stream);
+                          nullptr, nullptr, OutcGrad{nullptr, nullptr, 0}, stream);
+}
+
+// The same pass with dout = gradient of the 1x1 output conv's input recomputed from dlogits (see OutcGrad above).
+extern "C" int insar_bnrelu_bwd_apply_outc(const float* dlogits, const float* wout, int32_t K, const InsarAct* y,
+                                           const float* scale, const float* shift, const float* mean, const float* invstd,
+                                           const float* gate, const float* coefB, const float* k1, const float* k2,
+                                           const InsarAct* dy, int32_t relu, void* stream) {
+  int rc;
+  if ((rc = insar_check_act(y, "insar_bnrelu_bwd_apply_outc", "y"))) return rc;
+  if ((rc = check_outc_grad(y, dlogits, wout, K, "insar_bnrelu_bwd_apply_outc"))) return rc;
+  return launch_bwd_apply("insar_bnrelu_bwd_apply_outc", nullptr, y, scale, shift, mean, invstd, gate, coefB, k1, k2, dy, relu,
+                          nullptr, nullptr, OutcGrad{dlogits, wout, K}, stream);
 }
 
 // The same pass with k1 / k2 taken from stage 1's per-image partial sums (ws of insar_bnse_bwd_coef_stage, stage 1):
@@ -1106,7 +1230,7 @@ extern "C" int insar_bnrelu_bwd_apply_part(const InsarAct* dout, const InsarAct*
                                            const float* tb, const float* tg, const InsarAct* dy, int32_t relu, void* stream) {
   if (!tb) INSAR_FAIL(INSAR_E_ARG, "insar_bnrelu_bwd_apply_part: null partial sums");
   return launch_bwd_apply("insar_bnrelu_bwd_apply_part", dout, y, scale, shift, mean, invstd, gate, coefB, nullptr, nullptr, dy,
-                          relu, tb, tg, stream);
+                          relu, tb, tg, OutcGrad{nullptr, nullptr, 0}, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

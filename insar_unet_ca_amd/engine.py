@@ -240,6 +240,7 @@ PROFILER: Optional[KernelTimer] = None
 # latency gaps in backward, which is throughput-bound. Kept as an option (bitwise equal, tested), off by default.
 SPLIT_COEF = os.environ.get("INSAR_SPLIT_COEF", "0") == "1"
 # Measured: issuing a unit's weight gradient AFTER its input-gradient GEMM ("after") is 1.2 % slower (9.34 vs 9.23 ms).
+OUTC_FUSE = os.environ.get("INSAR_OUTC_FUSE", "1") != "0"        # diagnostic: 0 materialises the gradient of outc's input
 WGRAD_ROWS = os.environ.get("INSAR_WGRAD_ROWS", "1") != "0"      # diagnostic: 0 = per-tap weight-gradient kernel everywhere
 WGRAD_LATE = os.environ.get("INSAR_WGRAD_ORDER", "before") == "after"      # diagnostic / tuning switch, see ConvBN.backward
 
@@ -458,13 +459,21 @@ class ConvBN:
              _lib.stream_ptr())
 
     # ---- backward -------------------------------------------------------------------------------
-    def backward(self, dout: Act, sink: GradSink, training: bool, se: Optional["SEState"], dx: Optional[Act]) -> None:
-        """dout: gradient wrt this unit's output (after ReLU and, if `se`, the SE gate)."""
+    def backward(self, dout: Optional[Act], sink: GradSink, training: bool, se: Optional["SEState"], dx: Optional[Act],
+                 outc_grad=None) -> None:
+        """dout: gradient wrt this unit's output (after ReLU and, if `se`, the SE gate); or `outc_grad` =
+        (dlogits, outc weight, K) when this unit feeds the 1x1 output conv: the reduce and apply passes then recompute
+        that gradient from dlogits instead of reading a 64-channel tensor (csrc/pointwise.hip, OutcGrad)."""
         ctx, s = self.ctx, _lib.stream_ptr()
         B, H, W = self.x.B, self.x.H, self.x.W
         if self.dy is None:
             self.dy = Act.alloc(B, H, W, self.cout, ctx.dtype, ctx.device)
-        call("insar_bnrelu_bwd_reduce", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.red_part), 1, self.red_rpp, s)
+        if outc_grad is not None:
+            dl, wout, K = outc_grad
+            call("insar_bnrelu_bwd_reduce_outc", ptr(dl), ptr(wout), K, self.y.ref, ptr(self.scale), ptr(self.shift),
+                 ptr(self.red_part), 1, self.red_rpp, s)
+        else:
+            call("insar_bnrelu_bwd_reduce", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.red_part), 1, self.red_rpp, s)
         d = InsarBnSeBwd()
         d.B, d.H, d.W, d.C = B, H, W, self.cout
         d.Cr = se.cr if se else 1
@@ -483,7 +492,7 @@ class ConvBN:
                      dbias, int(training))
         # Training mode: only the per-image stage stays on the dgrad chain; the apply pass folds k1 / k2 from its
         # partial sums itself and the batch fold (parameter gradients) follows the weight gradient on the side stream.
-        split = training and SPLIT_COEF and self.cout <= 1024
+        split = training and SPLIT_COEF and self.cout <= 1024 and outc_grad is None
         stage2 = None
         if split:
             call("insar_bnse_bwd_coef_stage", *coef_args, 1, s)
@@ -492,6 +501,11 @@ class ConvBN:
                  ptr(self.invstd), ptr(se.gate) if se else 0, ptr(se.coefB) if se else 0, tb, tb + 4 * B * self.cout,
                  self.dy.ref, 1, s)
             stage2 = lambda: call("insar_bnse_bwd_coef_stage", *coef_args, 2, _lib.stream_ptr())
+        elif outc_grad is not None:
+            call("insar_bnse_bwd_coef", *coef_args, s)
+            call("insar_bnrelu_bwd_apply_outc", ptr(dl), ptr(wout), K, self.y.ref, ptr(self.scale), ptr(self.shift),
+                 ptr(self.mean), ptr(self.invstd), ptr(se.gate) if se else 0, ptr(se.coefB) if se else 0, ptr(self.k1),
+                 ptr(self.k2), self.dy.ref, 1, s)
         else:
             call("insar_bnse_bwd_coef", *coef_args, s)
             call("insar_bnrelu_bwd_apply", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.mean),
@@ -628,10 +642,10 @@ class DoubleConvPlan:
         else:
             self.u2.apply(self.out, None, self.pool_out)
 
-    def backward(self, dout: Act, sink: GradSink, training: bool, dx: Optional[Act]) -> None:
+    def backward(self, dout: Optional[Act], sink: GradSink, training: bool, dx: Optional[Act], outc_grad=None) -> None:
         if self.dz1 is None:
             self.dz1 = Act.alloc(self.x.B, self.x.H, self.x.W, self.u1.cout, self.ctx.dtype, self.ctx.device)
-        self.u2.backward(dout, sink, training, self.se, self.dz1)
+        self.u2.backward(dout, sink, training, self.se, self.dz1, outc_grad)
         self.u1.backward(self.dz1, sink, training, None, dx)
 
 
@@ -713,15 +727,32 @@ class OutConvPlan:
              ptr(self.mod.bias.detach()) if self.mod.bias is not None else 0, ptr(logits), self.K, _lib.stream_ptr())
         return logits
 
-    def backward(self, dlogits: torch.Tensor, sink: GradSink, dx: Act) -> None:
-        call("insar_conv1x1_out_bwd", self.x.ref, ptr(self.mod.weight.detach()), ptr(dlogits), self.K, dx.ref,
-             ptr(self.part), _lib.stream_ptr())
-        with self.ctx.side_stream():            # folds are off the critical path
+    def backward(self, dlogits: torch.Tensor, sink: GradSink, dx: Optional[Act]) -> None:
+        """dx = None: only outc's parameter gradients (side stream); the unit below recomputes its incoming gradient
+        from dlogits (ConvBN.backward, outc_grad)."""
+        def fold():
             self.ctx.colsum(self.part, self.folded, 1, self.nb, self.cols)
             kc = self.K * self.cin
             sink.view(self.mod.weight).view(-1).copy_(self.folded[:kc])
             if self.mod.bias is not None:
                 sink.view(self.mod.bias).copy_(self.folded[kc:])
+
+        if dx is None:
+            if self.ctx.side is not None and PROFILER is None and dlogits.is_cuda:
+                dlogits.record_stream(self.ctx.side)      # read on the side stream after the caller has dropped it
+            with self.ctx.side_stream():
+                call("insar_conv1x1_out_wgrad", self.x.ref, ptr(self.mod.weight.detach()), ptr(dlogits), self.K,
+                     ptr(self.part), _lib.stream_ptr())
+                fold()
+            return
+        call("insar_conv1x1_out_bwd", self.x.ref, ptr(self.mod.weight.detach()), ptr(dlogits), self.K, dx.ref,
+             ptr(self.part), _lib.stream_ptr())
+        with self.ctx.side_stream():            # folds are off the critical path
+            fold()
+
+    def virtual_grad_ok(self) -> bool:
+        ch = 16 // self.ctx.esize
+        return OUTC_FUSE and self.K <= 4 and self.cin % ch == 0 and 256 % (self.cin // ch) == 0
 
 
 def pack_input(x: torch.Tensor, dst: Act) -> None:
@@ -838,10 +869,12 @@ class UNetPlan:
             dlogits = dlogits.float().contiguous()
         sink, training, w = self.sink, self.training, self.widths
         sink.select()
-        self.outc.backward(dlogits, sink, self.ddec[0])
+        fuse = self.outc.virtual_grad_ok()
+        self.outc.backward(dlogits, sink, None if fuse else self.ddec[0])
         for i in (3, 2, 1, 0):
             l = 3 - i
-            self.dconv[i].backward(self.ddec[l], sink, training, self.dcat[l])
+            og = (dlogits, self.net.outc.weight.detach(), self.outc.K) if (fuse and i == 3) else None
+            self.dconv[i].backward(None if og else self.ddec[l], sink, training, self.dcat[l], og)
             dsrc = self.dx5 if i == 0 else self.ddec[l + 1]
             self.up[i].backward(self.dcat[l].slice(w[l], w[l]), sink, dsrc)
             if on_bucket is not None:

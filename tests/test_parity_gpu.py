@@ -926,6 +926,28 @@ def test_split_backward_coefficients_are_bitwise_the_fused_launch(dev, dtype, mo
     assert all(torch.equal(a, b) for a, b in zip(*grads))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_recomputed_outc_gradient_is_bitwise_the_materialised_one(dev, dtype, monkeypatch):
+    """The unit below outc recomputes its incoming gradient from dlogits inside its BatchNorm-backward passes
+    (insar_bnrelu_bwd_reduce_outc / _apply_outc, insar_conv1x1_out_wgrad): same bits as insar_conv1x1_out_bwd writing
+    the 64-channel tensor and the plain passes reading it, for every parameter gradient."""
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd import engine
+    from insar_unet_ca_amd.data import make_batch
+    x, y = make_batch(7, 3, 48)
+    x, y = x.to(dev), y.to(dev)
+    grads = []
+    for fuse in (True, False):
+        monkeypatch.setattr(engine, "OUTC_FUSE", fuse)
+        torch.manual_seed(11)
+        net = iu.UNet(2, 2, True, compute_dtype=dtype).to(dev).train()
+        loss = iu.DiceCELoss(ignore_index=255)(net(x), y)
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append([p.grad.clone() for p in net.parameters()])
+    assert all(torch.equal(a, b) for a, b in zip(*grads))
+
+
 def test_step_reproducible_over_many_runs_with_side_stream(dev):
     """Race screen for the two-stream step (weight gradients beside the dgrad chain): 150 repeats of fwd+bwd on
     fixed weights must give ONE set of gradient bits. (Regression: a wave passed the K-step barrier of the 64x64
