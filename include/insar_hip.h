@@ -283,6 +283,14 @@ int insar_bnrelu_bwd_apply_part(const InsarAct* dout, const InsarAct* y, const f
  * gradients (part as insar_conv1x1_out_bwd) without writing that tensor. Bitwise the same results as
  * insar_conv1x1_out_bwd + insar_bnrelu_bwd_reduce + insar_bnrelu_bwd_apply, three activation-sized HBM passes less. */
 int insar_conv1x1_out_wgrad(const InsarAct* x, const float* w, const float* dlogits, int32_t K, float* part, void* stream);
+/* Forward counterpart: the last unit's BN/ReLU/gate pass hands z straight to outc and writes only the logits
+ * (fp32 [B][K][H][W], K <= 4; bitwise insar_bn_relu_apply + insar_conv1x1_out_fwd); outc's parameter gradients then
+ * come from insar_conv1x1_out_wgrad_y, which recomputes z = round(relu(y*scale+shift) * gate[n]) from y. */
+int insar_bn_relu_apply_outc(const InsarAct* y, const float* scale, const float* shift, const float* gate /*nullable*/,
+                             const float* wout, const float* bias /*nullable*/, float* logits, int32_t K, int32_t relu,
+                             void* stream);
+int insar_conv1x1_out_wgrad_y(const InsarAct* y, const float* scale, const float* shift, const float* gate /*nullable*/,
+                              const float* w, const float* dlogits, int32_t K, float* part, void* stream);
 int insar_bnrelu_bwd_reduce_outc(const float* dlogits, const float* wout, int32_t K, const InsarAct* y,
                                  const float* scale, const float* shift, float* part, int32_t relu,
                                  int32_t rows_per_part, void* stream);

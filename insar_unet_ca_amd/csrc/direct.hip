@@ -464,9 +464,13 @@ extern "C" int insar_conv1x1_out_fwd(const InsarAct* x, const float* w, const fl
 // outc backward: dx[n,h,w,c] = sum_k dl[n,k,h,w] W[k][c];  dW[k][c] = sum dl*x;  db[k] = sum dl
 // part[block][K*C + K] partial sums (one row per block), folded by insar_colsum.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+// FROMY: x holds the raw conv output y of the last unit and outc's input is recomputed,
+//   z = round_T(relu(y*scale + shift) * gate[n]), instead of read (insar_bn_relu_apply_outc does not store it).
+template <typename T, bool FROMY = false>
 __global__ void conv1x1_out_bwd_kernel(ActView x, const float* __restrict__ wt, const float* __restrict__ dl,
-                                       int K, ActView dx, float* __restrict__ part) {
+                                       int K, ActView dx, float* __restrict__ part,
+                                       const float* __restrict__ zscale = nullptr, const float* __restrict__ zshift = nullptr,
+                                       const float* __restrict__ zgate = nullptr) {
   constexpr int CH = Chunk<T>::N;
   extern __shared__ float sm[];                     // [K][C] weights, then [4][K*C + K] partials
   const int C = x.c_len;
@@ -493,6 +497,15 @@ __global__ void conv1x1_out_bwd_kernel(ActView x, const float* __restrict__ wt, 
       const int w = e / cpp;
       float f[CH], o[CH];
       Chunk<T>::unpack(*(const uint4*)(x.base + (x.elem_offset(n, h, w) + (int64_t)cc * CH) * (int64_t)sizeof(T)), f);
+      if constexpr (FROMY) {
+        float zz[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const int c = cc * CH + j;
+          zz[j] = fmaxf(fmaf(f[j], zscale[c], zshift[c]), 0.f) * (zgate ? zgate[(int64_t)n * C + c] : 1.f);
+        }
+        Chunk<T>::unpack(Chunk<T>::pack(zz), f);
+      }
 #pragma unroll
       for (int j = 0; j < CH; ++j) o[j] = 0.f;
 #pragma unroll
@@ -586,5 +599,22 @@ extern "C" int insar_conv1x1_out_wgrad(const InsarAct* x, const float* w, const 
   if (x->dtype == INSAR_BF16) hipLaunchKernelGGL(conv1x1_out_bwd_kernel<bf16_t>, dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), w, dlogits, K, none, part);
   else hipLaunchKernelGGL(conv1x1_out_bwd_kernel<float>, dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), w, dlogits, K, none, part);
   INSAR_CHECK_LAUNCH("insar_conv1x1_out_wgrad");
+  return INSAR_OK;
+}
+
+// The same with outc's input recomputed from the last unit's raw conv output: z = round(relu(y*scale+shift) * gate[n])
+// (gate nullable), the companion of insar_bn_relu_apply_outc.
+extern "C" int insar_conv1x1_out_wgrad_y(const InsarAct* y, const float* scale, const float* shift, const float* gate,
+                                         const float* w, const float* dlogits, int32_t K, float* part, void* stream) {
+  int rc;
+  if ((rc = check_out(y, K, "insar_conv1x1_out_wgrad_y"))) return rc;
+  if (!w || !dlogits || !part || !scale || !shift) INSAR_FAIL(INSAR_E_ARG, "insar_conv1x1_out_wgrad_y: null pointer");
+  size_t lds = (size_t)(K * y->c_len + 4 * (K * y->c_len + K)) * sizeof(float);
+  int grid = insar_conv1x1_out_bwd_blocks(y->B, y->H);
+  hipStream_t s = (hipStream_t)stream;
+  ActView none = make_view(*y); none.base = nullptr;
+  if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((conv1x1_out_bwd_kernel<bf16_t, true>), dim3(grid), dim3(DR_THREADS), lds, s, make_view(*y), w, dlogits, K, none, part, scale, shift, gate);
+  else hipLaunchKernelGGL((conv1x1_out_bwd_kernel<float, true>), dim3(grid), dim3(DR_THREADS), lds, s, make_view(*y), w, dlogits, K, none, part, scale, shift, gate);
+  INSAR_CHECK_LAUNCH("insar_conv1x1_out_wgrad_y");
   return INSAR_OK;
 }

@@ -583,6 +583,94 @@ extern "C" int insar_bn_relu_apply_pool(const InsarAct* y, const float* scale, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// z = relu(y*scale + shift) * gate of the LAST unit, consumed on the spot by the 1x1 output conv (outc,
+// Unet-ChannalAttention.py:125,162): logits[n,k,h,w] = bias[k] + sum_c round_T(z[c]) * W[k][c], fp32 NCHW. z itself is
+// not written: backward needs only y (insar_conv1x1_out_wgrad_y recomputes z). The 8 (bf16) / 16 (fp32) lanes that
+// share a pixel reduce their partial dot products exactly as conv1x1_out_fwd_kernel does (fma chain over the chunk,
+// xor-shuffle tree over the chunks), so the logits are bitwise those of apply + insar_conv1x1_out_fwd.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int KM>
+__global__ void __launch_bounds__(512) bn_relu_apply_outc_kernel(ActView y, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, const float* __restrict__ gate,
+                                                                 const float* __restrict__ wout, const float* __restrict__ bias,
+                                                                 float* __restrict__ logits, int K, int relu) {
+  constexpr int CH = Chunk<T>::N;
+  const int cpp = y.c_len / CH;                       // host guarantees: power of two, <= 64, divides blockDim
+  const int rows = y.B * y.H;
+  const int cc = threadIdx.x % cpp, wstep = blockDim.x / cpp;
+  const int64_t HW = (int64_t)y.H * y.W;
+  float sc[CH], sh[CH], gt[CH], wk[KM][CH], bk[KM];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { sc[j] = scale[cc * CH + j]; sh[j] = shift[cc * CH + j]; gt[j] = 1.f; }
+#pragma unroll
+  for (int k = 0; k < KM; ++k) {
+    bk[k] = (bias && k < K) ? bias[k] : 0.f;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) wk[k][j] = k < K ? wout[k * y.c_len + cc * CH + j] : 0.f;
+  }
+  const int wpad = (y.W + wstep - 1) / wstep * wstep;      // whole waves take part in the shuffles
+  int n_loaded = -1;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int n = r / y.H, h = r - n * y.H;
+    if (gate && n != n_loaded) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) gt[j] = gate[(int64_t)n * y.c_len + cc * CH + j];
+      n_loaded = n;
+    }
+    for (int w0 = threadIdx.x / cpp; w0 < wpad; w0 += PW_UNROLL * wstep) {
+      uint4 v[PW_UNROLL];
+#pragma unroll
+      for (int u = 0; u < PW_UNROLL; ++u)
+        if (w0 + u * wstep < y.W) v[u] = *chunk_ptr<T>(y, n, h, w0 + u * wstep, cc);
+#pragma unroll
+      for (int u = 0; u < PW_UNROLL; ++u) {
+        const int w = w0 + u * wstep;
+        if (w >= wpad) continue;
+        const bool ok = w < y.W;
+        float f[CH], z[CH];
+        if (ok) Chunk<T>::unpack(v[u], f);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const float t = ok ? fmaf(f[j], sc[j], sh[j]) : 0.f;
+          f[j] = (relu ? fmaxf(t, 0.f) : t) * gt[j];
+        }
+        Chunk<T>::unpack(Chunk<T>::pack(f), z);            // the rounding a stored z would have had
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+          if (k < K) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) a = fmaf(z[j], wk[k][j], a);
+            for (int o = 1; o < cpp; o <<= 1) a += __shfl_xor(a, o, 64);
+            if (ok && cc == 0) logits[((int64_t)n * K + k) * HW + (int64_t)h * y.W + w] = a + bk[k];
+          }
+      }
+    }
+  }
+}
+
+extern "C" int insar_bn_relu_apply_outc(const InsarAct* y, const float* scale, const float* shift, const float* gate,
+                                        const float* wout, const float* bias, float* logits, int32_t K, int32_t relu,
+                                        void* stream) {
+  int rc;
+  if ((rc = insar_check_act(y, "insar_bn_relu_apply_outc", "y"))) return rc;
+  if (!scale || !shift || !wout || !logits) INSAR_FAIL(INSAR_E_ARG, "insar_bn_relu_apply_outc: null pointer");
+  if (K < 1 || K > 4) INSAR_FAIL(INSAR_E_SHAPE, "insar_bn_relu_apply_outc: num_classes=%d must be 1..4", K);
+  const int ch = y->dtype == INSAR_BF16 ? 8 : 4;
+  const int cpp = y->c_len / ch;
+  if (y->c_len % ch || cpp < 1 || cpp > 64 || (cpp & (cpp - 1)) || PW_THREADS % cpp)
+    INSAR_FAIL(INSAR_E_SHAPE, "insar_bn_relu_apply_outc: C=%d unsupported", y->c_len);
+  int grid = insar_grid_cap((int64_t)y->B * y->H);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_AO(TT, KK) hipLaunchKernelGGL((bn_relu_apply_outc_kernel<TT, KK>), dim3(grid), dim3(PW_THREADS), 0, s, make_view(*y), scale, shift, gate, wout, bias, logits, K, relu)
+  if (y->dtype == INSAR_BF16) { if (K <= 2) LAUNCH_AO(bf16_t, 2); else LAUNCH_AO(bf16_t, 4); }
+  else { if (K <= 2) LAUNCH_AO(float, 2); else LAUNCH_AO(float, 4); }
+#undef LAUNCH_AO
+  INSAR_CHECK_LAUNCH("insar_bn_relu_apply_outc");
+  return INSAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // "Virtual" gradient of the 1x1 output conv (outc, Unet-ChannalAttention.py:125,162): the gradient wrt outc's input,
 //   g[n,h,w,c] = round_T( sum_k dlogits[n,k,h,w] * W[k][c] )        (k ascending, fma chain, as conv1x1_out_bwd stores it)
 // costs 2K multiply-adds per element, so the BatchNorm-backward reduce and apply passes of the unit that feeds outc

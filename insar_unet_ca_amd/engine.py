@@ -623,7 +623,9 @@ class DoubleConvPlan:
             ps += [self.se.fc1.weight, self.se.fc2.weight]
         return ps
 
-    def forward(self, training: bool) -> None:
+    def forward(self, training: bool, outc: Optional["OutConvPlan"] = None) -> Optional[torch.Tensor]:
+        """outc: the 1x1 output conv when this is the last block and its output goes nowhere else — the final
+        BN/ReLU/gate pass then writes the logits instead of `out` (returned)."""
         s = _lib.stream_ptr()
         self.u1.forward_conv(training)
         self.u1.apply(self.z1, None)
@@ -638,9 +640,14 @@ class DoubleConvPlan:
             d.w1, d.w2 = ptr(se.fc1.weight.detach()), ptr(se.fc2.weight.detach())
             d.sq, d.hid, d.gate = ptr(se.sq), ptr(se.hid), ptr(se.gate)
             call("insar_se_excite", C.byref(d), s)
+            if outc is not None:
+                return outc.forward_fused(u2, se.gate)
             u2.apply(self.out, se.gate, self.pool_out)
         else:
+            if outc is not None:
+                return outc.forward_fused(self.u2, None)
             self.u2.apply(self.out, None, self.pool_out)
+        return None
 
     def backward(self, dout: Optional[Act], sink: GradSink, training: bool, dx: Optional[Act], outc_grad=None) -> None:
         if self.dz1 is None:
@@ -716,15 +723,27 @@ class OutConvPlan:
         self.cols = self.K * self.cin + self.K
         self.part = ctx.f32(self.nb, self.cols)
         self.folded = ctx.f32(self.cols)
+        self.fused_src = None          # (unit, gate) when the last forward went through forward_fused
 
     def params(self):
         return [self.mod.weight, self.mod.bias]
 
     def forward(self) -> torch.Tensor:
+        self.fused_src = None
         x = self.x
         logits = torch.empty((x.B, self.K, x.H, x.W), dtype=torch.float32, device=self.ctx.device)
         call("insar_conv1x1_out_fwd", x.ref, ptr(self.mod.weight.detach()),
              ptr(self.mod.bias.detach()) if self.mod.bias is not None else 0, ptr(logits), self.K, _lib.stream_ptr())
+        return logits
+
+    def forward_fused(self, unit: "ConvBN", gate: Optional[torch.Tensor]) -> torch.Tensor:
+        """logits straight from the last unit's raw conv output (its BN/ReLU/gate pass and outc in one launch; the
+        unit's output activation is never written)."""
+        y = unit.y
+        logits = torch.empty((y.B, self.K, y.H, y.W), dtype=torch.float32, device=self.ctx.device)
+        call("insar_bn_relu_apply_outc", y.ref, ptr(unit.scale), ptr(unit.shift), ptr(gate), ptr(self.mod.weight.detach()),
+             ptr(self.mod.bias.detach()) if self.mod.bias is not None else 0, ptr(logits), self.K, 1, _lib.stream_ptr())
+        self.fused_src = (unit, gate)
         return logits
 
     def backward(self, dlogits: torch.Tensor, sink: GradSink, dx: Optional[Act]) -> None:
@@ -741,8 +760,13 @@ class OutConvPlan:
             if self.ctx.side is not None and PROFILER is None and dlogits.is_cuda:
                 dlogits.record_stream(self.ctx.side)      # read on the side stream after the caller has dropped it
             with self.ctx.side_stream():
-                call("insar_conv1x1_out_wgrad", self.x.ref, ptr(self.mod.weight.detach()), ptr(dlogits), self.K,
-                     ptr(self.part), _lib.stream_ptr())
+                if self.fused_src is not None:       # the input activation was never stored: recompute it from y
+                    unit, gate = self.fused_src
+                    call("insar_conv1x1_out_wgrad_y", unit.y.ref, ptr(unit.scale), ptr(unit.shift), ptr(gate),
+                         ptr(self.mod.weight.detach()), ptr(dlogits), self.K, ptr(self.part), _lib.stream_ptr())
+                else:
+                    call("insar_conv1x1_out_wgrad", self.x.ref, ptr(self.mod.weight.detach()), ptr(dlogits), self.K,
+                         ptr(self.part), _lib.stream_ptr())
                 fold()
             return
         call("insar_conv1x1_out_bwd", self.x.ref, ptr(self.mod.weight.detach()), ptr(dlogits), self.K, dx.ref,
@@ -857,9 +881,13 @@ class UNetPlan:
         pack_input(x, self.xin)
         for l in range(5):
             self.enc[l].forward(training)          # levels 0-3 write their max-pool too (pool_out)
-        for i in range(4):
+        for i in range(3):
             self.up[i].forward()
             self.dconv[i].forward(training)
+        self.up[3].forward()
+        if self.outc.virtual_grad_ok():      # last block: BN/ReLU/gate + outc in one pass, no 64-channel output tensor
+            return self.dconv[3].forward(training, self.outc)
+        self.dconv[3].forward(training)
         return self.outc.forward()
 
     # ---- backward ---------------------------------------------------------------------------------

@@ -116,7 +116,9 @@ def test_plan_launch_sequence(mocked_abi):
     assert c["insar_bn_relu_apply_pool"] == 4 and c["insar_maxpool2_bwd"] == 4     # pool forward rides on the apply pass
     # the unit that feeds outc recomputes its incoming gradient from dlogits; outc only produces its parameter gradients
     assert c["insar_bnse_bwd_coef"] == 18 and c["insar_bnrelu_bwd_apply"] == 17 and c["insar_bnrelu_bwd_apply_outc"] == 1
-    assert c["insar_bnrelu_bwd_reduce_outc"] == 1 and c["insar_conv1x1_out_wgrad"] == 1 and c.get("insar_conv1x1_out_bwd", 0) == 0
+    assert c["insar_bnrelu_bwd_reduce_outc"] == 1 and c["insar_conv1x1_out_wgrad_y"] == 1 and c.get("insar_conv1x1_out_bwd", 0) == 0
+    # ... and in forward its BN/ReLU/gate pass writes the logits itself (no 64-channel output tensor, no separate outc launch)
+    assert c["insar_bn_relu_apply_outc"] == 1 and c.get("insar_conv1x1_out_fwd", 0) == 0
     assert all(p.grad is not None and p.grad.shape == p.shape for p in net.parameters())
     # gradients alias the plan's flat buffer (no per-step clone) and the next backward must not clobber them
     plan = net._plan(x)

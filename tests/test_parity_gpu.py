@@ -582,7 +582,11 @@ def test_unet_fp32_gradients_given_equal_relu_decisions(dev, fixture, shape):
     for names, blocks in zip(_BLOCK_NAMES, (plan.enc, plan.dconv)):
         for name, blk in zip(names, blocks):
             given_masks["relu", f"{name}.double_conv.1"] = blk.z1.nchw().cpu() > 0
-            given_masks["relu", f"{name}.double_conv.4"] = blk.out.nchw().cpu() > 0   # gate = sigmoid(.) > 0 keeps the sign
+            # the decision rule of the path: fma(y, scale, shift) > 0 (its exact sign, in float64). The last block's
+            # output is never stored (its BN/ReLU/gate pass writes the logits), so the stored activation is not used here.
+            u2 = blk.u2
+            pre = u2.y.nchw().double() * u2.scale.double().view(1, -1, 1, 1) + u2.shift.double().view(1, -1, 1, 1)
+            given_masks["relu", f"{name}.double_conv.4"] = (pre > 0).cpu()
             given_masks["se_relu", f"{name}.double_conv.6"] = blk.se.hid.cpu() > 0
     for i in range(1, 5):       # arg-max of each pool window, from the HIP path's own activations (torch's tie rule)
         given_idx[f"down{i}.0"] = F.max_pool2d(plan.enc[i - 1].out.nchw().cpu(), 2, return_indices=True)[1]
@@ -936,15 +940,20 @@ def test_recomputed_outc_gradient_is_bitwise_the_materialised_one(dev, dtype, mo
     from insar_unet_ca_amd.data import make_batch
     x, y = make_batch(7, 3, 48)
     x, y = x.to(dev), y.to(dev)
-    grads = []
+    grads, outs = [], []
     for fuse in (True, False):
         monkeypatch.setattr(engine, "OUTC_FUSE", fuse)
         torch.manual_seed(11)
         net = iu.UNet(2, 2, True, compute_dtype=dtype).to(dev).train()
-        loss = iu.DiceCELoss(ignore_index=255)(net(x), y)
+        logits = net(x)                                  # fused: written by the last unit's BN/ReLU/gate pass itself
+        loss = iu.DiceCELoss(ignore_index=255)(logits, y)
         loss.backward()
         torch.cuda.synchronize()
         grads.append([p.grad.clone() for p in net.parameters()])
+        net.eval()
+        with torch.no_grad():
+            outs.append((logits.detach().clone(), net(x).clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert all(torch.equal(a, b) for a, b in zip(*grads))
 
 
