@@ -276,6 +276,23 @@ int insar_bnrelu_bwd_apply_part(const InsarAct* dout, const InsarAct* y, const f
                                 const float* mean, const float* invstd, const float* gate, const float* coefB,
                                 const float* tb, const float* tg, const InsarAct* dy, int32_t relu, void* stream);
 
+/* ---- MaxPool2d(2) backward inside the encoder block's BatchNorm-backward passes -----------------------------------
+ * insar_bn_relu_apply_pool_arg is insar_bn_relu_apply_pool that also records which element of each 2x2 window is
+ * the maximum (arg[B][H/2][W/2][C] bytes 0..3 = 2*(row parity) + (column parity); insar_maxpool2_bwd's rule on the
+ * stored values). The _pool variants of the reduce and apply passes then take
+ *   dout = round_T(dskip + (arg == position ? dpooled : 0))
+ * on the fly — the expression insar_maxpool2_bwd evaluates when it accumulates into dskip — so that launch (a read of
+ * the full-resolution activation and a read-modify-write of its gradient) is not needed. Bitwise the same results. */
+int insar_bn_relu_apply_pool_arg(const InsarAct* y, const float* scale, const float* shift, const float* gate,
+                                 const InsarAct* dst, const InsarAct* pooled, uint8_t* arg, int32_t relu, void* stream);
+int insar_bnrelu_bwd_reduce_pool(const InsarAct* dskip, const InsarAct* dpooled, const uint8_t* arg, const InsarAct* y,
+                                 const float* scale, const float* shift, float* part, int32_t relu,
+                                 int32_t rows_per_part, void* stream);
+int insar_bnrelu_bwd_apply_pool(const InsarAct* dskip, const InsarAct* dpooled, const uint8_t* arg, const InsarAct* y,
+                                const float* scale, const float* shift, const float* mean, const float* invstd,
+                                const float* gate, const float* coefB, const float* k1, const float* k2,
+                                const InsarAct* dy, int32_t relu, void* stream);
+
 /* ---- the unit that feeds the 1x1 output conv (outc, Unet-ChannalAttention.py:125,162) ----------------------------
  * Its incoming gradient is g[n,h,w,c] = round_T(sum_k dlogits[n,k,h,w] * W[k][c]): 2K multiply-adds per element, so the
  * reduce and apply passes recompute it from dlogits (fp32 [B][K][H][W], K <= 4) and outc's weight ([K][C] fp32)

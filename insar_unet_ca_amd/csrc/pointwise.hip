@@ -522,7 +522,8 @@ extern "C" int insar_bn_relu_apply(const InsarAct* y, const float* scale, const 
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void bn_relu_apply_pool_kernel(ActView y, const float* __restrict__ scale, const float* __restrict__ shift,
-                                          const float* __restrict__ gate, ActView dst, ActView pooled, int relu) {
+                                          const float* __restrict__ gate, ActView dst, ActView pooled, int relu,
+                                          uint8_t* __restrict__ arg) {
   constexpr int CH = Chunk<T>::N;
   const int cpp = y.c_len / CH;
   const int Hp = y.H / 2, Wp2 = y.W / 2;
@@ -543,10 +544,11 @@ __global__ void bn_relu_apply_pool_kernel(ActView y, const float* __restrict__ s
       uint4 v[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = *chunk_ptr<T>(y, n, 2 * h2 + (q >> 1), 2 * w2 + (q & 1), cc);
-      float m[CH];
+      float m[CH], mr[CH];
+      uint32_t best[CH];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float f[CH];
+        float f[CH], fr[CH];
         Chunk<T>::unpack(v[q], f);
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
@@ -554,15 +556,35 @@ __global__ void bn_relu_apply_pool_kernel(ActView y, const float* __restrict__ s
           f[j] = (relu ? fmaxf(z, 0.f) : z) * gt[j];
           m[j] = q == 0 ? f[j] : fmaxf(m[j], f[j]);
         }
-        *chunk_ptr_w<T>(dst, n, 2 * h2 + (q >> 1), 2 * w2 + (q & 1), cc) = Chunk<T>::pack(f);
+        const uint4 packed = Chunk<T>::pack(f);
+        *chunk_ptr_w<T>(dst, n, 2 * h2 + (q >> 1), 2 * w2 + (q & 1), cc) = packed;
+        if (arg) {           // arg-max of the STORED values, insar_maxpool2_bwd's rule: first maximum in scan order, NaN wins
+          Chunk<T>::unpack(packed, fr);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            if (q == 0) { mr[j] = fr[j]; best[j] = 0; }
+            else if (fr[j] > mr[j] || fr[j] != fr[j]) { mr[j] = fr[j]; best[j] = q; }
+          }
+        }
       }
       *chunk_ptr_w<T>(pooled, n, h2, w2, cc) = Chunk<T>::pack(m);
+      if (arg) {
+        uint8_t* ap = arg + (((int64_t)n * Hp + h2) * Wp2 + w2) * y.c_len + cc * CH;      // [B][H/2][W/2][C] bytes
+        if constexpr (CH == 8) {
+          uint2 u;
+          u.x = best[0] | (best[1] << 8) | (best[2] << 16) | (best[3] << 24);
+          u.y = best[4] | (best[5] << 8) | (best[6] << 16) | (best[7] << 24);
+          *(uint2*)ap = u;
+        } else {
+          *(uint32_t*)ap = best[0] | (best[1] << 8) | (best[2] << 16) | (best[3] << 24);
+        }
+      }
     }
   }
 }
 
-extern "C" int insar_bn_relu_apply_pool(const InsarAct* y, const float* scale, const float* shift, const float* gate,
-                                        const InsarAct* dst, const InsarAct* pooled, int32_t relu, void* stream) {
+static int launch_apply_pool(const InsarAct* y, const float* scale, const float* shift, const float* gate,
+                             const InsarAct* dst, const InsarAct* pooled, int32_t relu, uint8_t* arg, void* stream) {
   int rc;
   if ((rc = insar_check_act(y, "insar_bn_relu_apply_pool", "y"))) return rc;
   if ((rc = insar_check_act(dst, "insar_bn_relu_apply_pool", "dst"))) return rc;
@@ -576,10 +598,26 @@ extern "C" int insar_bn_relu_apply_pool(const InsarAct* y, const float* scale, c
   if (PW_THREADS % (y->c_len / ch)) INSAR_FAIL(INSAR_E_SHAPE, "insar_bn_relu_apply_pool: C=%d unsupported", y->c_len);
   int grid = insar_grid_cap((int64_t)y->B * (y->H / 2));
   hipStream_t s = (hipStream_t)stream;
-  if (y->dtype == INSAR_BF16) hipLaunchKernelGGL(bn_relu_apply_pool_kernel<bf16_t>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*y), scale, shift, gate, make_view(*dst), make_view(*pooled), relu);
-  else hipLaunchKernelGGL(bn_relu_apply_pool_kernel<float>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*y), scale, shift, gate, make_view(*dst), make_view(*pooled), relu);
+  if (y->dtype == INSAR_BF16) hipLaunchKernelGGL(bn_relu_apply_pool_kernel<bf16_t>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*y), scale, shift, gate, make_view(*dst), make_view(*pooled), relu, arg);
+  else hipLaunchKernelGGL(bn_relu_apply_pool_kernel<float>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*y), scale, shift, gate, make_view(*dst), make_view(*pooled), relu, arg);
   INSAR_CHECK_LAUNCH("insar_bn_relu_apply_pool");
   return INSAR_OK;
+}
+
+extern "C" int insar_bn_relu_apply_pool(const InsarAct* y, const float* scale, const float* shift, const float* gate,
+                                        const InsarAct* dst, const InsarAct* pooled, int32_t relu, void* stream) {
+  return launch_apply_pool(y, scale, shift, gate, dst, pooled, relu, nullptr, stream);
+}
+
+// The same pass, also recording WHICH element of each 2x2 window is the maximum (insar_maxpool2_bwd's rule on the
+// stored values): arg[B][H/2][W/2][C] bytes in 0..3 = 2*(row parity) + (column parity). With it the pooled gradient is
+// routed inside the BatchNorm-backward passes of this unit (insar_bnrelu_bwd_reduce_pool / _apply_pool) and
+// insar_maxpool2_bwd (one read of the full-resolution activation, a read-modify-write of its gradient) is not needed.
+extern "C" int insar_bn_relu_apply_pool_arg(const InsarAct* y, const float* scale, const float* shift, const float* gate,
+                                            const InsarAct* dst, const InsarAct* pooled, uint8_t* arg, int32_t relu,
+                                            void* stream) {
+  if (!arg) INSAR_FAIL(INSAR_E_ARG, "insar_bn_relu_apply_pool_arg: null arg map");
+  return launch_apply_pool(y, scale, shift, gate, dst, pooled, relu, arg, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -677,6 +715,34 @@ extern "C" int insar_bn_relu_apply_outc(const InsarAct* y, const float* scale, c
 // recompute it from the K-channel fp32 dlogits instead of reading a materialised 64-channel tensor twice (and
 // conv1x1_out_bwd does not write it): 3 activation-sized HBM passes less per step, bitwise the same numbers.
 // ---------------------------------------------------------------------------------------------
+// "Virtual" sum of the two gradients that meet at an encoder block's output: the skip gradient g (stored) and the
+// max-pool gradient, routed by the forward pass's arg-max map:  gg = round_T(g + (arg == position ? dp : 0))
+// (the expression insar_maxpool2_bwd evaluates when it accumulates into g).
+struct PoolGrad {
+  ActView dp;           // gradient wrt the pooled activation (B, H/2, W/2, C)
+  const uint8_t* arg;   // [B][H/2][W/2][C] bytes 0..3, or null: no pooled gradient
+};
+template <typename T>
+__device__ __forceinline__ void pool_grad_chunk(const uint4& vdp, const uint8_t* argp, int pos, float (&gg)[Chunk<T>::N]) {
+  constexpr int CH = Chunk<T>::N;
+  float dpf[CH];
+  Chunk<T>::unpack(vdp, dpf);
+  uint32_t a[CH];
+  if constexpr (CH == 8) {
+    const uint2 u = *(const uint2*)argp;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = (u.x >> (8 * j)) & 0xffu; a[4 + j] = (u.y >> (8 * j)) & 0xffu; }
+  } else {
+    const uint32_t u = *(const uint32_t*)argp;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = (u >> (8 * j)) & 0xffu;
+  }
+  float o[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) o[j] = gg[j] + ((int)a[j] == pos ? dpf[j] : 0.f);
+  Chunk<T>::unpack(Chunk<T>::pack(o), gg);
+}
+
 #define OG_MAXK 4
 struct OutcGrad {
   const float* dl;      // [B][K][H][W] fp32, or null: read the gradient tensor
@@ -707,10 +773,10 @@ __device__ __forceinline__ void outc_grad_chunk(const float (&dlv)[KM], const fl
 // ---------------------------------------------------------------------------------------------
 // VK = 0: dout read from memory; VK = 2 / 4: dout recomputed from dlogits with K <= VK classes (own instantiations with
 // their own register budget: the plain passes keep theirs)
-template <typename T, bool WITH_G, int VK = 0>
-__global__ void __launch_bounds__(VK ? 512 : 1024) row_reduce_kernel(ActView g, ActView y, const float* __restrict__ scale,
+template <typename T, bool WITH_G, int VK = 0, bool VP = false>
+__global__ void __launch_bounds__((VK || VP) ? 512 : 1024) row_reduce_kernel(ActView g, ActView y, const float* __restrict__ scale,
                                   const float* __restrict__ shift, float* __restrict__ part, int relu, int rpp,
-                                  OutcGrad og) {
+                                  OutcGrad og, PoolGrad pg) {
   constexpr int CH = Chunk<T>::N;
   __shared__ float red[PW_THREADS][2 * CH + 1];
   const int cpp = y.c_len / CH;
@@ -738,7 +804,7 @@ __global__ void __launch_bounds__(VK ? 512 : 1024) row_reduce_kernel(ActView g, 
       const int wstep = blockDim.x / cpp;
       for (int h = h0; h < h1; ++h) {
         for (int w0 = threadIdx.x / cpp; w0 < y.W; w0 += PW_UNROLL * wstep) {
-          uint4 vy[PW_UNROLL], vg[PW_UNROLL];
+          uint4 vy[PW_UNROLL], vg[PW_UNROLL], vp[VP ? PW_UNROLL : 1];
           float dlv[PW_UNROLL][KM];
 #pragma unroll
           for (int u = 0; u < PW_UNROLL; ++u)
@@ -750,6 +816,7 @@ __global__ void __launch_bounds__(VK ? 512 : 1024) row_reduce_kernel(ActView g, 
                   if (k < og.K) dlv[u][k] = og.dl[((int64_t)n * og.K + k) * HW + (int64_t)h * y.W + w0 + u * wstep];
               } else if constexpr (WITH_G) {
                 vg[u] = *chunk_ptr<T>(g, n, h, w0 + u * wstep, cc);
+                if constexpr (VP) vp[u] = *chunk_ptr<T>(pg.dp, n, h >> 1, (w0 + u * wstep) >> 1, cc);
               }
             }
 #pragma unroll
@@ -759,6 +826,11 @@ __global__ void __launch_bounds__(VK ? 512 : 1024) row_reduce_kernel(ActView g, 
               Chunk<T>::unpack(vy[u], f);
               if constexpr (virt) outc_grad_chunk<T, KM>(dlv[u], wk, og.K, gg);
               else if constexpr (WITH_G) Chunk<T>::unpack(vg[u], gg);
+              if constexpr (VP) {
+                const int w = w0 + u * wstep;
+                pool_grad_chunk<T>(vp[u], pg.arg + ((((int64_t)n * (y.H >> 1) + (h >> 1)) * (y.W >> 1) + (w >> 1)) * y.c_len + cc * CH),
+                                   ((h & 1) << 1) | (w & 1), gg);
+              }
 #pragma unroll
               for (int j = 0; j < CH; ++j) {
                 const bool on = !relu || fmaf(f[j], sc[j], sh[j]) > 0.f;
@@ -814,8 +886,8 @@ extern "C" int insar_se_squeeze(const InsarAct* y, const float* scale, const flo
   int grid = insar_grid_cap((int64_t)y->B * ((y->H + rpp - 1) / rpp));
   hipStream_t s = (hipStream_t)stream;
   ActView v = make_view(*y);
-  if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, false>), dim3(grid), dim3(PW_THREADS), 0, s, v, v, scale, shift, part, relu, rpp, OutcGrad{nullptr, nullptr, 0});
-  else hipLaunchKernelGGL((row_reduce_kernel<float, false>), dim3(grid), dim3(PW_THREADS), 0, s, v, v, scale, shift, part, relu, rpp, OutcGrad{nullptr, nullptr, 0});
+  if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, false>), dim3(grid), dim3(PW_THREADS), 0, s, v, v, scale, shift, part, relu, rpp, OutcGrad{nullptr, nullptr, 0}, PoolGrad{ActView{}, nullptr});
+  else hipLaunchKernelGGL((row_reduce_kernel<float, false>), dim3(grid), dim3(PW_THREADS), 0, s, v, v, scale, shift, part, relu, rpp, OutcGrad{nullptr, nullptr, 0}, PoolGrad{ActView{}, nullptr});
   INSAR_CHECK_LAUNCH("insar_se_squeeze");
   return INSAR_OK;
 }
@@ -828,8 +900,19 @@ static int check_outc_grad(const InsarAct* y, const float* dlogits, const float*
   return INSAR_OK;
 }
 
+static int check_pool_grad(const InsarAct* y, const InsarAct* dp, const uint8_t* arg, const char* who) {
+  int rc;
+  if (!dp || !arg) INSAR_FAIL(INSAR_E_ARG, "%s: null pooled gradient / arg-max map", who);
+  if ((rc = insar_check_act(dp, who, "dpooled"))) return rc;
+  if ((y->H & 1) || (y->W & 1) || dp->B != y->B || dp->H != y->H / 2 || dp->W != y->W / 2 || dp->c_len != y->c_len || dp->dtype != y->dtype)
+    INSAR_FAIL(INSAR_E_SHAPE, "%s: pooled gradient must be (B, H/2, W/2, C) of an even grid", who);
+  const int ch = y->dtype == INSAR_BF16 ? 8 : 4;
+  if (y->c_len % ch || PW_THREADS % (y->c_len / ch)) INSAR_FAIL(INSAR_E_SHAPE, "%s: C=%d unsupported", who, y->c_len);
+  return INSAR_OK;
+}
+
 static int launch_bwd_reduce(const char* who, const InsarAct* dout, const InsarAct* y, const float* scale, const float* shift,
-                             float* part, int32_t relu, int32_t rows_per_part, OutcGrad og, void* stream) {
+                             float* part, int32_t relu, int32_t rows_per_part, OutcGrad og, PoolGrad pg, void* stream) {
   int rc;
   if ((rc = insar_check_act(y, who, "y"))) return rc;
   if (!og.dl) {
@@ -843,14 +926,17 @@ static int launch_bwd_reduce(const char* who, const InsarAct* dout, const InsarA
   hipStream_t s = (hipStream_t)stream;
   const ActView vy = make_view(*y), vg = og.dl ? vy : make_view(*dout);
   if (og.dl && og.K <= 2) {
-    if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, true, 2>), dim3(grid), dim3(PW_THREADS), 0, s, vg, vy, scale, shift, part, relu, rpp, og);
-    else hipLaunchKernelGGL((row_reduce_kernel<float, true, 2>), dim3(grid), dim3(PW_THREADS), 0, s, vg, vy, scale, shift, part, relu, rpp, og);
+    if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, true, 2>), dim3(grid), dim3(PW_THREADS), 0, s, vg, vy, scale, shift, part, relu, rpp, og, pg);
+    else hipLaunchKernelGGL((row_reduce_kernel<float, true, 2>), dim3(grid), dim3(PW_THREADS), 0, s, vg, vy, scale, shift, part, relu, rpp, og, pg);
   } else if (og.dl) {
-    if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, true, OG_MAXK>), dim3(grid), dim3(PW_THREADS), 0, s, vg, vy, scale, shift, part, relu, rpp, og);
-    else hipLaunchKernelGGL((row_reduce_kernel<float, true, OG_MAXK>), dim3(grid), dim3(PW_THREADS), 0, s, vg, vy, scale, shift, part, relu, rpp, og);
+    if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, true, OG_MAXK>), dim3(grid), dim3(PW_THREADS), 0, s, vg, vy, scale, shift, part, relu, rpp, og, pg);
+    else hipLaunchKernelGGL((row_reduce_kernel<float, true, OG_MAXK>), dim3(grid), dim3(PW_THREADS), 0, s, vg, vy, scale, shift, part, relu, rpp, og, pg);
+  } else if (pg.arg) {
+    if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, true, 0, true>), dim3(grid), dim3(PW_THREADS), 0, s, vg, vy, scale, shift, part, relu, rpp, og, pg);
+    else hipLaunchKernelGGL((row_reduce_kernel<float, true, 0, true>), dim3(grid), dim3(PW_THREADS), 0, s, vg, vy, scale, shift, part, relu, rpp, og, pg);
   } else {
-    if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, true>), dim3(grid), dim3(PW_THREADS), 0, s, vg, vy, scale, shift, part, relu, rpp, og);
-    else hipLaunchKernelGGL((row_reduce_kernel<float, true>), dim3(grid), dim3(PW_THREADS), 0, s, vg, vy, scale, shift, part, relu, rpp, og);
+    if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, true>), dim3(grid), dim3(PW_THREADS), 0, s, vg, vy, scale, shift, part, relu, rpp, og, pg);
+    else hipLaunchKernelGGL((row_reduce_kernel<float, true>), dim3(grid), dim3(PW_THREADS), 0, s, vg, vy, scale, shift, part, relu, rpp, og, pg);
   }
   INSAR_CHECK_LAUNCH(who);
   return INSAR_OK;
@@ -859,7 +945,20 @@ static int launch_bwd_reduce(const char* who, const InsarAct* dout, const InsarA
 extern "C" int insar_bnrelu_bwd_reduce(const InsarAct* dout, const InsarAct* y, const float* scale, const float* shift,
                                        float* part, int32_t relu, int32_t rows_per_part, void* stream) {
   return launch_bwd_reduce("insar_bnrelu_bwd_reduce", dout, y, scale, shift, part, relu, rows_per_part,
-                           OutcGrad{nullptr, nullptr, 0}, stream);
+                           OutcGrad{nullptr, nullptr, 0}, PoolGrad{ActView{}, nullptr}, stream);
+}
+
+// The same sums with dout = round(dskip + (arg == position ? dpooled : 0)): the gradient that reaches an encoder block's
+// output through its skip connection plus the one routed back through MaxPool2d(2) (Unet-ChannalAttention.py:106-109)
+// by the arg-max map of insar_bn_relu_apply_pool_arg, summed on the fly instead of by insar_maxpool2_bwd.
+extern "C" int insar_bnrelu_bwd_reduce_pool(const InsarAct* dskip, const InsarAct* dpooled, const uint8_t* arg, const InsarAct* y,
+                                            const float* scale, const float* shift, float* part, int32_t relu,
+                                            int32_t rows_per_part, void* stream) {
+  int rc;
+  if ((rc = insar_check_act(y, "insar_bnrelu_bwd_reduce_pool", "y"))) return rc;
+  if ((rc = check_pool_grad(y, dpooled, arg, "insar_bnrelu_bwd_reduce_pool"))) return rc;
+  return launch_bwd_reduce("insar_bnrelu_bwd_reduce_pool", dskip, y, scale, shift, part, relu, rows_per_part,
+                           OutcGrad{nullptr, nullptr, 0}, PoolGrad{make_view(*dpooled), arg}, stream);
 }
 
 // The same sums with dout = gradient of the 1x1 output conv's input, recomputed from dlogits [B][K][H][W] (fp32) and
@@ -871,7 +970,7 @@ extern "C" int insar_bnrelu_bwd_reduce_outc(const float* dlogits, const float* w
   if ((rc = insar_check_act(y, "insar_bnrelu_bwd_reduce_outc", "y"))) return rc;
   if ((rc = check_outc_grad(y, dlogits, wout, K, "insar_bnrelu_bwd_reduce_outc"))) return rc;
   return launch_bwd_reduce("insar_bnrelu_bwd_reduce_outc", nullptr, y, scale, shift, part, relu, rows_per_part,
-                           OutcGrad{dlogits, wout, K}, stream);
+                           OutcGrad{dlogits, wout, K}, PoolGrad{ActView{}, nullptr}, stream);
 }
 
 // Sum `rows` rows of a [rows][cols] fp32 slab into out[cols] (LDS), all threads of the block cooperating:
@@ -1144,13 +1243,13 @@ extern "C" int insar_bnse_bwd_coef_stage(const InsarBnSeBwd* d, const float* red
 
 // dy = scale * ( (dout*gate + coefB) * mask - k1 - xhat*k2 ),  xhat = (y - mean)*invstd
 #define BWD_APPLY_MAXC 1024
-template <typename T, int VK = 0>       // VK as in row_reduce_kernel
-__global__ void __launch_bounds__(VK ? 512 : 1024) bnrelu_bwd_apply_kernel(ActView g, ActView y, const float* __restrict__ scale,
+template <typename T, int VK = 0, bool VP = false>       // VK, VP as in row_reduce_kernel
+__global__ void __launch_bounds__((VK || VP) ? 512 : 1024) bnrelu_bwd_apply_kernel(ActView g, ActView y, const float* __restrict__ scale,
                                         const float* __restrict__ shift, const float* __restrict__ mean,
                                         const float* __restrict__ invstd, const float* __restrict__ gate,
                                         const float* __restrict__ coefB, const float* k1,
                                         const float* k2, ActView dy, int relu,
-                                        const float* __restrict__ tb, const float* __restrict__ tg, OutcGrad og) {
+                                        const float* __restrict__ tb, const float* __restrict__ tg, OutcGrad og, PoolGrad pg) {
   constexpr int CH = Chunk<T>::N;
   const int cpp = y.c_len / CH;
   const int rows = y.B * y.H;
@@ -1201,7 +1300,7 @@ __global__ void __launch_bounds__(VK ? 512 : 1024) bnrelu_bwd_apply_kernel(ActVi
         n_loaded = n;
       }
       for (int w0 = threadIdx.x / cpp; w0 < y.W; w0 += PW_UNROLL * wstep) {
-        uint4 vy[PW_UNROLL], vg[PW_UNROLL];
+        uint4 vy[PW_UNROLL], vg[PW_UNROLL], vp[VP ? PW_UNROLL : 1];
         float dlv[PW_UNROLL][KM];
 #pragma unroll
         for (int u = 0; u < PW_UNROLL; ++u)
@@ -1213,6 +1312,7 @@ __global__ void __launch_bounds__(VK ? 512 : 1024) bnrelu_bwd_apply_kernel(ActVi
                 if (k < og.K) dlv[u][k] = og.dl[((int64_t)n * og.K + k) * HW + (int64_t)h * y.W + w0 + u * wstep];
             } else {
               vg[u] = *chunk_ptr<T>(g, n, h, w0 + u * wstep, cc);
+              if constexpr (VP) vp[u] = *chunk_ptr<T>(pg.dp, n, h >> 1, (w0 + u * wstep) >> 1, cc);
             }
           }
 #pragma unroll
@@ -1222,6 +1322,11 @@ __global__ void __launch_bounds__(VK ? 512 : 1024) bnrelu_bwd_apply_kernel(ActVi
             Chunk<T>::unpack(vy[u], f);
             if constexpr (virt) outc_grad_chunk<T, KM>(dlv[u], wk, og.K, gg);
             else Chunk<T>::unpack(vg[u], gg);
+            if constexpr (VP) {
+              const int w = w0 + u * wstep;
+              pool_grad_chunk<T>(vp[u], pg.arg + ((((int64_t)n * (y.H >> 1) + (h >> 1)) * (y.W >> 1) + (w >> 1)) * y.c_len + cc * CH),
+                                 ((h & 1) << 1) | (w & 1), gg);
+            }
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
               const bool on = !relu || fmaf(f[j], sc[j], sh[j]) > 0.f;
@@ -1264,7 +1369,7 @@ __global__ void __launch_bounds__(VK ? 512 : 1024) bnrelu_bwd_apply_kernel(ActVi
 static int launch_bwd_apply(const char* who, const InsarAct* dout, const InsarAct* y, const float* scale, const float* shift,
                             const float* mean, const float* invstd, const float* gate, const float* coefB,
                             const float* k1, const float* k2, const InsarAct* dy, int32_t relu,
-                            const float* tb, const float* tg, OutcGrad og, void* stream) {
+                            const float* tb, const float* tg, OutcGrad og, PoolGrad pg, void* stream) {
   int rc;
   if ((rc = insar_check_act(y, who, "y"))) return rc;
   if (!og.dl) {
@@ -1279,15 +1384,20 @@ static int launch_bwd_apply(const char* who, const InsarAct* dout, const InsarAc
     INSAR_FAIL(INSAR_E_SHAPE, "%s: partial sums need tg and C <= %d", who, BWD_APPLY_MAXC);
   int grid = insar_grid_cap((int64_t)y->B * y->H);
   hipStream_t s = (hipStream_t)stream;
-#define LAUNCH_APPLY_VK(TT, VKK) hipLaunchKernelGGL((bnrelu_bwd_apply_kernel<TT, VKK>), dim3(grid), dim3(PW_THREADS), 0, s, make_view(*y), make_view(*y), scale, shift, mean, invstd, gate, coefB, k1, k2, make_view(*dy), relu, tb, tg, og)
+#define LAUNCH_APPLY_VK(TT, VKK) hipLaunchKernelGGL((bnrelu_bwd_apply_kernel<TT, VKK>), dim3(grid), dim3(PW_THREADS), 0, s, make_view(*y), make_view(*y), scale, shift, mean, invstd, gate, coefB, k1, k2, make_view(*dy), relu, tb, tg, og, pg)
   if (og.dl) {
     if (y->dtype == INSAR_BF16) { if (og.K <= 2) LAUNCH_APPLY_VK(bf16_t, 2); else LAUNCH_APPLY_VK(bf16_t, OG_MAXK); }
     else { if (og.K <= 2) LAUNCH_APPLY_VK(float, 2); else LAUNCH_APPLY_VK(float, OG_MAXK); }
 #undef LAUNCH_APPLY_VK
+  } else if (pg.arg) {
+    if (y->dtype == INSAR_BF16)
+      hipLaunchKernelGGL((bnrelu_bwd_apply_kernel<bf16_t, 0, true>), dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, mean, invstd, gate, coefB, k1, k2, make_view(*dy), relu, tb, tg, og, pg);
+    else
+      hipLaunchKernelGGL((bnrelu_bwd_apply_kernel<float, 0, true>), dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, mean, invstd, gate, coefB, k1, k2, make_view(*dy), relu, tb, tg, og, pg);
   } else if (y->dtype == INSAR_BF16)
-    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, mean, invstd, gate, coefB, k1, k2, make_view(*dy), relu, tb, tg, og);
+    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, mean, invstd, gate, coefB, k1, k2, make_view(*dy), relu, tb, tg, og, pg);
   else
-    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel<float>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, mean, invstd, gate, coefB, k1, k2, make_view(*dy), relu, tb, tg, og);
+    hipLaunchKernelGGL(bnrelu_bwd_apply_kernel<float>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*dout), make_view(*y), scale, shift, mean, invstd, gate, coefB, k1, k2, make_view(*dy), relu, tb, tg, og, pg);
   INSAR_CHECK_LAUNCH(who);
   return INSAR_OK;
 }
@@ -1296,7 +1406,19 @@ extern "C" int insar_bnrelu_bwd_apply(const InsarAct* dout, const InsarAct* y, c
                                       const float* mean, const float* invstd, const float* gate, const float* coefB,
                                       const float* k1, const float* k2, const InsarAct* dy, int32_t relu, void* stream) {
   return launch_bwd_apply("insar_bnrelu_bwd_apply", dout, y, scale, shift, mean, invstd, gate, coefB, k1, k2, dy, relu,
-                          nullptr, nullptr, OutcGrad{nullptr, nullptr, 0}, stream);
+                          nullptr, nullptr, OutcGrad{nullptr, nullptr, 0}, PoolGrad{ActView{}, nullptr}, stream);
+}
+
+// The same pass with dout = round(dskip + (arg == position ? dpooled : 0)) (see insar_bnrelu_bwd_reduce_pool).
+extern "C" int insar_bnrelu_bwd_apply_pool(const InsarAct* dskip, const InsarAct* dpooled, const uint8_t* arg, const InsarAct* y,
+                                           const float* scale, const float* shift, const float* mean, const float* invstd,
+                                           const float* gate, const float* coefB, const float* k1, const float* k2,
+                                           const InsarAct* dy, int32_t relu, void* stream) {
+  int rc;
+  if ((rc = insar_check_act(y, "insar_bnrelu_bwd_apply_pool", "y"))) return rc;
+  if ((rc = check_pool_grad(y, dpooled, arg, "insar_bnrelu_bwd_apply_pool"))) return rc;
+  return launch_bwd_apply("insar_bnrelu_bwd_apply_pool", dskip, y, scale, shift, mean, invstd, gate, coefB, k1, k2, dy, relu,
+                          nullptr, nullptr, OutcGrad{nullptr, nullptr, 0}, PoolGrad{make_view(*dpooled), arg}, stream);
 }
 
 // The same pass with dout = gradient of the 1x1 output conv's input recomputed from dlogits (see OutcGrad above).
@@ -1308,7 +1430,7 @@ extern "C" int insar_bnrelu_bwd_apply_outc(const float* dlogits, const float* wo
   if ((rc = insar_check_act(y, "insar_bnrelu_bwd_apply_outc", "y"))) return rc;
   if ((rc = check_outc_grad(y, dlogits, wout, K, "insar_bnrelu_bwd_apply_outc"))) return rc;
   return launch_bwd_apply("insar_bnrelu_bwd_apply_outc", nullptr, y, scale, shift, mean, invstd, gate, coefB, k1, k2, dy, relu,
-                          nullptr, nullptr, OutcGrad{dlogits, wout, K}, stream);
+                          nullptr, nullptr, OutcGrad{dlogits, wout, K}, PoolGrad{ActView{}, nullptr}, stream);
 }
 
 // The same pass with k1 / k2 taken from stage 1's per-image partial sums (ws of insar_bnse_bwd_coef_stage, stage 1):
@@ -1318,7 +1440,7 @@ extern "C" int insar_bnrelu_bwd_apply_part(const InsarAct* dout, const InsarAct*
                                            const float* tb, const float* tg, const InsarAct* dy, int32_t relu, void* stream) {
   if (!tb) INSAR_FAIL(INSAR_E_ARG, "insar_bnrelu_bwd_apply_part: null partial sums");
   return launch_bwd_apply("insar_bnrelu_bwd_apply_part", dout, y, scale, shift, mean, invstd, gate, coefB, nullptr, nullptr, dy,
-                          relu, tb, tg, OutcGrad{nullptr, nullptr, 0}, stream);
+                          relu, tb, tg, OutcGrad{nullptr, nullptr, 0}, PoolGrad{ActView{}, nullptr}, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

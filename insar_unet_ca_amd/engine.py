@@ -240,6 +240,7 @@ PROFILER: Optional[KernelTimer] = None
 # latency gaps in backward, which is throughput-bound. Kept as an option (bitwise equal, tested), off by default.
 SPLIT_COEF = os.environ.get("INSAR_SPLIT_COEF", "0") == "1"
 # Measured: issuing a unit's weight gradient AFTER its input-gradient GEMM ("after") is 1.2 % slower (9.34 vs 9.23 ms).
+POOL_FUSE = os.environ.get("INSAR_POOL_FUSE", "1") != "0"        # diagnostic: 0 routes the max-pool gradient with insar_maxpool2_bwd
 OUTC_FUSE = os.environ.get("INSAR_OUTC_FUSE", "1") != "0"        # diagnostic: 0 materialises the gradient of outc's input
 WGRAD_ROWS = os.environ.get("INSAR_WGRAD_ROWS", "1") != "0"      # diagnostic: 0 = per-tap weight-gradient kernel everywhere
 WGRAD_LATE = os.environ.get("INSAR_WGRAD_ORDER", "before") == "after"      # diagnostic / tuning switch, see ConvBN.backward
@@ -450,17 +451,22 @@ class ConvBN:
         d.scale, d.shift, d.mean, d.invstd = ptr(self.scale), ptr(self.shift), ptr(self.mean), ptr(self.invstd)
         call("insar_bn_finalize", C.byref(d), s)
 
-    def apply(self, dst: Act, gate: Optional[torch.Tensor], pooled: Optional[Act] = None) -> None:
+    def apply(self, dst: Act, gate: Optional[torch.Tensor], pooled: Optional[Act] = None,
+              pool_arg: Optional[torch.Tensor] = None) -> None:
         if pooled is not None:          # encoder block: the 2x2 max-pool of dst comes out of the same pass
-            call("insar_bn_relu_apply_pool", self.y.ref, ptr(self.scale), ptr(self.shift), ptr(gate), dst.ref,
-                 pooled.ref, 1, _lib.stream_ptr())
+            if pool_arg is not None:    # ... with its arg-max map, for the backward passes of this unit
+                call("insar_bn_relu_apply_pool_arg", self.y.ref, ptr(self.scale), ptr(self.shift), ptr(gate), dst.ref,
+                     pooled.ref, ptr(pool_arg), 1, _lib.stream_ptr())
+            else:
+                call("insar_bn_relu_apply_pool", self.y.ref, ptr(self.scale), ptr(self.shift), ptr(gate), dst.ref,
+                     pooled.ref, 1, _lib.stream_ptr())
             return
         call("insar_bn_relu_apply", self.y.ref, ptr(self.scale), ptr(self.shift), ptr(gate), dst.ref, 1,
              _lib.stream_ptr())
 
     # ---- backward -------------------------------------------------------------------------------
     def backward(self, dout: Optional[Act], sink: GradSink, training: bool, se: Optional["SEState"], dx: Optional[Act],
-                 outc_grad=None) -> None:
+                 outc_grad=None, pool_grad=None) -> None:
         """dout: gradient wrt this unit's output (after ReLU and, if `se`, the SE gate); or `outc_grad` =
         (dlogits, outc weight, K) when this unit feeds the 1x1 output conv: the reduce and apply passes then recompute
         that gradient from dlogits instead of reading a 64-channel tensor (csrc/pointwise.hip, OutcGrad)."""
@@ -471,6 +477,11 @@ class ConvBN:
         if outc_grad is not None:
             dl, wout, K = outc_grad
             call("insar_bnrelu_bwd_reduce_outc", ptr(dl), ptr(wout), K, self.y.ref, ptr(self.scale), ptr(self.shift),
+                 ptr(self.red_part), 1, self.red_rpp, s)
+        elif pool_grad is not None:
+            # encoder block: dout = skip gradient + the max-pool gradient routed by the forward arg-max map, summed on the fly
+            dpool, parg = pool_grad
+            call("insar_bnrelu_bwd_reduce_pool", dout.ref, dpool.ref, ptr(parg), self.y.ref, ptr(self.scale), ptr(self.shift),
                  ptr(self.red_part), 1, self.red_rpp, s)
         else:
             call("insar_bnrelu_bwd_reduce", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.red_part), 1, self.red_rpp, s)
@@ -492,7 +503,7 @@ class ConvBN:
                      dbias, int(training))
         # Training mode: only the per-image stage stays on the dgrad chain; the apply pass folds k1 / k2 from its
         # partial sums itself and the batch fold (parameter gradients) follows the weight gradient on the side stream.
-        split = training and SPLIT_COEF and self.cout <= 1024 and outc_grad is None
+        split = training and SPLIT_COEF and self.cout <= 1024 and outc_grad is None and pool_grad is None
         stage2 = None
         if split:
             call("insar_bnse_bwd_coef_stage", *coef_args, 1, s)
@@ -504,6 +515,11 @@ class ConvBN:
         elif outc_grad is not None:
             call("insar_bnse_bwd_coef", *coef_args, s)
             call("insar_bnrelu_bwd_apply_outc", ptr(dl), ptr(wout), K, self.y.ref, ptr(self.scale), ptr(self.shift),
+                 ptr(self.mean), ptr(self.invstd), ptr(se.gate) if se else 0, ptr(se.coefB) if se else 0, ptr(self.k1),
+                 ptr(self.k2), self.dy.ref, 1, s)
+        elif pool_grad is not None:
+            call("insar_bnse_bwd_coef", *coef_args, s)
+            call("insar_bnrelu_bwd_apply_pool", dout.ref, dpool.ref, ptr(parg), self.y.ref, ptr(self.scale), ptr(self.shift),
                  ptr(self.mean), ptr(self.invstd), ptr(se.gate) if se else 0, ptr(se.coefB) if se else 0, ptr(self.k1),
                  ptr(self.k2), self.dy.ref, 1, s)
         else:
@@ -606,6 +622,7 @@ class DoubleConvPlan:
     def __init__(self, ctx: Ctx, mod, x: Act, out: Act, name: str):
         self.ctx, self.mod, self.x, self.out, self.name = ctx, mod, x, out, name
         self.pool_out: Optional[Act] = None      # set by the plan for encoder blocks: MaxPool2d(2) of `out`
+        self.pool_arg: Optional[torch.Tensor] = None   # ... and its arg-max byte map (B, H/2, W/2, C), see POOL_FUSE
         seq = mod.double_conv
         self.u1 = ConvBN(ctx, seq[0], seq[1], x, name + ".0")
         self.z1 = Act.alloc(x.B, x.H, x.W, self.u1.cout, ctx.dtype, ctx.device)
@@ -642,17 +659,18 @@ class DoubleConvPlan:
             call("insar_se_excite", C.byref(d), s)
             if outc is not None:
                 return outc.forward_fused(u2, se.gate)
-            u2.apply(self.out, se.gate, self.pool_out)
+            u2.apply(self.out, se.gate, self.pool_out, self.pool_arg)
         else:
             if outc is not None:
                 return outc.forward_fused(self.u2, None)
-            self.u2.apply(self.out, None, self.pool_out)
+            self.u2.apply(self.out, None, self.pool_out, self.pool_arg)
         return None
 
-    def backward(self, dout: Optional[Act], sink: GradSink, training: bool, dx: Optional[Act], outc_grad=None) -> None:
+    def backward(self, dout: Optional[Act], sink: GradSink, training: bool, dx: Optional[Act], outc_grad=None,
+                 pool_grad=None) -> None:
         if self.dz1 is None:
             self.dz1 = Act.alloc(self.x.B, self.x.H, self.x.W, self.u1.cout, self.ctx.dtype, self.ctx.device)
-        self.u2.backward(dout, sink, training, self.se, self.dz1, outc_grad)
+        self.u2.backward(dout, sink, training, self.se, self.dz1, outc_grad, pool_grad)
         self.u1.backward(self.dz1, sink, training, None, dx)
 
 
@@ -831,6 +849,9 @@ class UNetPlan:
             self.enc.append(DoubleConvPlan(ctx, enc_mods[l], xin, out, enc_names[l]))
             if l < 4:
                 self.enc[l].pool_out = self.pooled[l]
+                ch = 16 // ctx.esize
+                if POOL_FUSE and widths[l] % ch == 0 and 256 % (widths[l] // ch) == 0:
+                    self.enc[l].pool_arg = torch.zeros((B, hs[l + 1], ws[l + 1], widths[l]), dtype=torch.uint8, device=device)
         ups = [net.up1, net.up2, net.up3, net.up4]
         convs = [net.conv1, net.conv2, net.conv3, net.conv4]
         self.up: List[UpPlan] = []
@@ -909,8 +930,11 @@ class UNetPlan:
                 on_bucket(self, ("dec", i))
         for l in (4, 3, 2, 1, 0):
             dout = self.dx5 if l == 4 else self.dcat[l].slice(0, w[l])
-            self.enc[l].backward(dout, sink, training, self.dpooled[l - 1] if l > 0 else None)
-            if l > 0:
+            # levels 0-3: the gradient through MaxPool2d(2) (dpooled[l], written by the level below) joins the skip
+            # gradient inside this block's BatchNorm-backward passes when the forward pass kept the arg-max map
+            pg = (self.dpooled[l], self.enc[l].pool_arg) if (l < 4 and self.enc[l].pool_arg is not None) else None
+            self.enc[l].backward(dout, sink, training, self.dpooled[l - 1] if l > 0 else None, None, pg)
+            if l > 0 and self.enc[l - 1].pool_arg is None:
                 call("insar_maxpool2_bwd", self.enc[l - 1].out.ref, self.dpooled[l - 1].ref,
                      self.dcat[l - 1].slice(0, w[l - 1]).ref, 1, s())
             if on_bucket is not None:

@@ -113,9 +113,11 @@ def test_plan_launch_sequence(mocked_abi):
     assert c["insar_wgrad"] == 17 + 4
     assert c["insar_conv3x3_small_fwd"] == 1 and c["insar_conv3x3_small_wgrad"] == 1
     assert c["insar_bn_finalize"] == 18 and c["insar_se_excite"] == 9
-    assert c["insar_bn_relu_apply_pool"] == 4 and c["insar_maxpool2_bwd"] == 4     # pool forward rides on the apply pass
+    # pool forward rides on the apply pass (with its arg-max map); pool backward rides on the reduce / apply passes
+    assert c["insar_bn_relu_apply_pool_arg"] == 4 and c.get("insar_maxpool2_bwd", 0) == 0
+    assert c["insar_bnrelu_bwd_reduce_pool"] == 4 and c["insar_bnrelu_bwd_apply_pool"] == 4
     # the unit that feeds outc recomputes its incoming gradient from dlogits; outc only produces its parameter gradients
-    assert c["insar_bnse_bwd_coef"] == 18 and c["insar_bnrelu_bwd_apply"] == 17 and c["insar_bnrelu_bwd_apply_outc"] == 1
+    assert c["insar_bnse_bwd_coef"] == 18 and c["insar_bnrelu_bwd_apply"] == 13 and c["insar_bnrelu_bwd_apply_outc"] == 1
     assert c["insar_bnrelu_bwd_reduce_outc"] == 1 and c["insar_conv1x1_out_wgrad_y"] == 1 and c.get("insar_conv1x1_out_bwd", 0) == 0
     # ... and in forward its BN/ReLU/gate pass writes the logits itself (no 64-channel output tensor, no separate outc launch)
     assert c["insar_bn_relu_apply_outc"] == 1 and c.get("insar_conv1x1_out_fwd", 0) == 0

@@ -957,6 +957,30 @@ def test_recomputed_outc_gradient_is_bitwise_the_materialised_one(dev, dtype, mo
     assert all(torch.equal(a, b) for a, b in zip(*grads))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pool_gradient_inside_bn_backward_is_bitwise_maxpool2_bwd(dev, dtype, monkeypatch):
+    """Arg-max map written by the forward apply+pool pass, pooled gradient added to the skip gradient on the fly in the
+    encoder blocks' BatchNorm-backward passes: same gradient bits as insar_maxpool2_bwd accumulating into the skip
+    gradient buffer first (the inputs contain exact ties: bf16 activations, ReLU zeros)."""
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd import engine
+    from insar_unet_ca_amd.data import make_batch
+    x, y = make_batch(5, 3, 48)
+    x, y = x.to(dev), y.to(dev)
+    grads = []
+    for fuse in (True, False):
+        monkeypatch.setattr(engine, "POOL_FUSE", fuse)
+        torch.manual_seed(3)
+        net = iu.UNet(2, 2, True, compute_dtype=dtype).to(dev).train()
+        loss = iu.DiceCELoss(ignore_index=255)(net(x), y)
+        loss.backward()
+        torch.cuda.synchronize()
+        plan = net._plan(x)
+        assert (plan.enc[0].pool_arg is not None) == fuse
+        grads.append([p.grad.clone() for p in net.parameters()])
+    assert all(torch.equal(a, b) for a, b in zip(*grads))
+
+
 def test_step_reproducible_over_many_runs_with_side_stream(dev):
     """Race screen for the two-stream step (weight gradients beside the dgrad chain): 150 repeats of fwd+bwd on
     fixed weights must give ONE set of gradient bits. (Regression: a wave passed the K-step barrier of the 64x64
