@@ -491,8 +491,19 @@ __global__ void conv1x1_out_bwd_kernel(ActView x, const float* __restrict__ wt, 
 #pragma unroll
     for (int j = 0; j < CH; ++j) aw[k][j] = 0.f;
   }
+  float zsc[CH], zsh[CH], zgt[CH];                   // FROMY: this thread's channel chunk never changes
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    zsc[j] = FROMY ? zscale[cc * CH + j] : 0.f; zsh[j] = FROMY ? zshift[cc * CH + j] : 0.f; zgt[j] = 1.f;
+  }
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const int n = r / x.H, h = r - n * x.H;
+    if constexpr (FROMY) {
+      if (zgate) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) zgt[j] = zgate[(int64_t)n * C + cc * CH + j];
+      }
+    }
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
       const int w = e / cpp;
       float f[CH], o[CH];
@@ -500,10 +511,7 @@ __global__ void conv1x1_out_bwd_kernel(ActView x, const float* __restrict__ wt, 
       if constexpr (FROMY) {
         float zz[CH];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-          const int c = cc * CH + j;
-          zz[j] = fmaxf(fmaf(f[j], zscale[c], zshift[c]), 0.f) * (zgate ? zgate[(int64_t)n * C + c] : 1.f);
-        }
+        for (int j = 0; j < CH; ++j) zz[j] = fmaxf(fmaf(f[j], zsc[j], zsh[j]), 0.f) * zgt[j];
         Chunk<T>::unpack(Chunk<T>::pack(zz), f);
       }
 #pragma unroll
