@@ -291,8 +291,9 @@ static inline int igemm_bm_for(long long M, int N) {
   const int bn = (N % 128) == 0 ? 128 : 64;
   const long long tiles256 = ((M + 255) / 256) * (N / bn);
   if (tiles256 >= 256) return 256;
-  // 256 x 64 tiles when they (and only they) fill the chip: still the 8-wave / 3-slab kernel
-  if (((M + 255) / 256) * (N / 64) >= 256) return 256;
+  // 256 x 64 tiles when they fill at least HALF the chip: still the 8-wave / 3-slab kernel (128 eight-wave
+  // work-groups beat 256 four-wave ones: the 16x16-level dgrad with N = 512 121 -> 96 us)
+  if (((M + 255) / 256) * (N / 64) >= 128) return 256;
   return 128;
 }
 // Output-channel tile: 128 wide where N allows, except on grids so small that 128x128 tiles would leave one
