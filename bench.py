@@ -202,7 +202,9 @@ def main() -> int:
                     "share_of_step": round(dom["ms"] / (1e3 * timed_elapsed), 4),
                     "measured": "HIP events around each launch on the launch stream, in a second pass of the same %d "
                                 "steps run on ONE stream (as with INSAR_SIDE_STREAM=0: per-kernel durations without "
-                                "the weight-gradient overlap; %.2f ms/step with events vs %.2f ms/step in the timed "
+                                "the weight-gradient overlap, weight gradients with the split-K factor that fills "
+                                "the chip; in the timed region they run beside the dgrad chain on half the slots; "
+                                "%.2f ms/step with events vs %.2f ms/step in the timed "
                                 "region); compare profiles/r01_bench_kernel_stats_single_stream.csv; traffic = "
                                 "rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per launch from profiles/r01_pmc_traffic.json" %
                                 (args.steps, 1e3 * timed_elapsed / args.steps, ms),

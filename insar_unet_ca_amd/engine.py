@@ -242,6 +242,8 @@ SPLIT_COEF = os.environ.get("INSAR_SPLIT_COEF", "0") == "1"
 # Measured: issuing a unit's weight gradient AFTER its input-gradient GEMM ("after") is 1.2 % slower (9.34 vs 9.23 ms).
 POOL_FUSE = os.environ.get("INSAR_POOL_FUSE", "1") != "0"        # diagnostic: 0 routes the max-pool gradient with insar_maxpool2_bwd
 OUTC_FUSE = os.environ.get("INSAR_OUTC_FUSE", "1") != "0"        # diagnostic: 0 materialises the gradient of outc's input
+WGRAD_FILL_T = float(os.environ.get("INSAR_WGRAD_FILL_T", "0.5"))   # the same for the transposed convs' per-tap weight gradient
+WGRAD_FILL = float(os.environ.get("INSAR_WGRAD_FILL", "0.5"))     # share of the work-group slots a side-stream weight gradient aims at
 WGRAD_ROWS = os.environ.get("INSAR_WGRAD_ROWS", "1") != "0"      # diagnostic: 0 = per-tap weight-gradient kernel everywhere
 WGRAD_LATE = os.environ.get("INSAR_WGRAD_ORDER", "before") == "after"      # diagnostic / tuning switch, see ConvBN.backward
 
@@ -315,7 +317,7 @@ def _rows_per_part(B: int, H: int) -> int:
 
 
 def _wgrad_nsplit(tiles: int, ksteps: int, slab_floats: int = 0, tm: int = 128, tn: int = 128, esize: int = 2,
-                  taps_per_wg: int = 1) -> int:
+                  taps_per_wg: int = 1, fill: float = 1.0) -> int:
     """Split-K factor for the weight-gradient GEMM. The grid is tiles*nsplit work-groups at two per CU
     (512 slots): pick the factor that minimises an estimate of
       GEMM time / (slot quantisation efficiency * main-loop share) + slab fold traffic."""
@@ -325,6 +327,7 @@ def _wgrad_nsplit(tiles: int, ksteps: int, slab_floats: int = 0, tm: int = 128, 
     slots = 256 * max(1, min(4, (160 * 1024) // lds))
     if taps_per_wg == 3 and tm * tn >= 128 * 128:
         slots = 256                                    # 8-wave work-groups, one per CU
+    slots = max(1, int(slots * fill))
     flops_per_step = 2.0 * tm * tn * 64 * taps_per_wg
     best, best_t = 1, float("inf")
     for n in range(1, max(1, min(ksteps // 4, 256)) + 1):
@@ -571,7 +574,12 @@ def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
         # three taps of a kernel row per work-group (csrc/wgrad3.hip): a third of the operand staging
         tm, tn = pair >> 16, pair & 0xffff
         tiles = 3 * (cin // tm) * (cout // tn)
-        nsplit = _wgrad_nsplit(tiles, B * H * W // WG_BKP, 9 * cout * cin, tm, tn, ctx.esize, taps_per_wg=3)
+        # Beside the dgrad chain (side stream) the weight gradient should fill about HALF the work-group slots: the
+        # main stream's kernels keep CUs, there are half as many slabs to fold, and the launch still ends before the
+        # next one is due (same-box sweep of the fill factor: 1.0 8.09-8.14, 0.7 7.86, 0.5 7.81-7.86, 0.35 7.86, 0.25
+        # 9.26 ms/step). Alone on the GPU (single-stream runs, the per-kernel event pass of bench.py) it fills the chip.
+        fill = WGRAD_FILL if (ctx.side is not None and PROFILER is None) else 1.0
+        nsplit = _wgrad_nsplit(tiles, B * H * W // WG_BKP, 9 * cout * cin, tm, tn, ctx.esize, taps_per_wg=3, fill=fill)
         part = ctx.wgrad_part(nsplit * 9 * cout * cin)
         if PROFILER is not None:
             tag = "wgrad3_kernel<%s, %d, %d, %d>" % ("float" if ctx.code == _lib.F32 else "bf16_t", tm, tn,
@@ -704,7 +712,8 @@ class UpPlan:
         mpad = tabx.numel()
         tm, tn = _wgrad_tiles(self.cin, self.cout, ctx.code)
         tiles = 4 * (self.cin // tm) * (self.cout // tn)
-        nsplit = _wgrad_nsplit(tiles, mpad // WG_BKP, 4 * self.cout * self.cin, tm, tn, ctx.esize)
+        fill = WGRAD_FILL_T if (ctx.side is not None and PROFILER is None) else 1.0
+        nsplit = _wgrad_nsplit(tiles, mpad // WG_BKP, 4 * self.cout * self.cin, tm, tn, ctx.esize, fill=fill)
         def weight_grad():
             with ctx.side_stream():
                 if self.mod.bias is not None:     # dbias = sum over pixels of dout (mask-free row reduction)
