@@ -243,6 +243,7 @@ SPLIT_COEF = os.environ.get("INSAR_SPLIT_COEF", "0") == "1"
 POOL_FUSE = os.environ.get("INSAR_POOL_FUSE", "1") != "0"        # diagnostic: 0 routes the max-pool gradient with insar_maxpool2_bwd
 OUTC_FUSE = os.environ.get("INSAR_OUTC_FUSE", "1") != "0"        # diagnostic: 0 materialises the gradient of outc's input
 WGRAD_FILL_T = float(os.environ.get("INSAR_WGRAD_FILL_T", "0.5"))   # the same for the transposed convs' per-tap weight gradient
+WGRAD_FILL_ALONE = float(os.environ.get("INSAR_WGRAD_FILL_ALONE", "1.0"))   # ... and when it has the GPU to itself
 WGRAD_FILL = float(os.environ.get("INSAR_WGRAD_FILL", "0.5"))     # share of the work-group slots a side-stream weight gradient aims at
 WGRAD_ROWS = os.environ.get("INSAR_WGRAD_ROWS", "1") != "0"      # diagnostic: 0 = per-tap weight-gradient kernel everywhere
 WGRAD_LATE = os.environ.get("INSAR_WGRAD_ORDER", "before") == "after"      # diagnostic / tuning switch, see ConvBN.backward
@@ -578,7 +579,7 @@ def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
         # main stream's kernels keep CUs, there are half as many slabs to fold, and the launch still ends before the
         # next one is due (same-box sweep of the fill factor: 1.0 8.09-8.14, 0.7 7.86, 0.5 7.81-7.86, 0.35 7.86, 0.25
         # 9.26 ms/step). Alone on the GPU (single-stream runs, the per-kernel event pass of bench.py) it fills the chip.
-        fill = WGRAD_FILL if (ctx.side is not None and PROFILER is None) else 1.0
+        fill = WGRAD_FILL if (ctx.side is not None and PROFILER is None) else WGRAD_FILL_ALONE
         nsplit = _wgrad_nsplit(tiles, B * H * W // WG_BKP, 9 * cout * cin, tm, tn, ctx.esize, taps_per_wg=3, fill=fill)
         part = ctx.wgrad_part(nsplit * 9 * cout * cin)
         if PROFILER is not None:

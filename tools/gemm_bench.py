@@ -23,6 +23,7 @@ def main():
     dev = torch.device("cuda:0")
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     ctx = engine.Ctx(dev, dtype)
+    ctx.side = None          # kernels measured alone: weight gradients get the split-K factor that fills the chip
     names = [n for n in a.only.split(",") if n] or list(LAYERS)
     what = a.what.split(",")
     for name in names:
