@@ -17,9 +17,9 @@ echo "== rocprof stats (default: two streams + event pass)"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/p1" -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/p1.log" 2>&1 || exit 1
 echo "== rocprof stats (single stream)"
 INSAR_SIDE_STREAM=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/p2" -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing > "$OUT/p2.log" 2>&1 || exit 1
-echo "== PMC passes"
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pF" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing > "$OUT/pF.log" 2>&1 || exit 1
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pW" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing > "$OUT/pW.log" 2>&1 || exit 1
+echo "== PMC passes (single stream: the launch configuration of the per-kernel event pass behind roofline.achieved)"
+INSAR_SIDE_STREAM=0 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pF" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing > "$OUT/pF.log" 2>&1 || exit 1
+INSAR_SIDE_STREAM=0 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pW" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing > "$OUT/pW.log" 2>&1 || exit 1
 cp $(ls "$OUT"/p1/*/*_kernel_stats.csv | head -n 1) "$OUT/bench_kernel_stats.csv"
 cp $(ls "$OUT"/p2/*/*_kernel_stats.csv | head -n 1) "$OUT/bench_kernel_stats_single_stream.csv"
 cp $(ls "$OUT"/pF/*/*_counter_collection.csv | head -n 1) "$OUT/pmc_fetch.csv"
