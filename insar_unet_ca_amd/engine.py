@@ -241,6 +241,7 @@ PROFILER: Optional[KernelTimer] = None
 SPLIT_COEF = os.environ.get("INSAR_SPLIT_COEF", "0") == "1"
 # Measured: issuing a unit's weight gradient AFTER its input-gradient GEMM ("after") is 1.2 % slower (9.34 vs 9.23 ms).
 POOL_FUSE = os.environ.get("INSAR_POOL_FUSE", "1") != "0"        # diagnostic: 0 routes the max-pool gradient with insar_maxpool2_bwd
+PREP_SIDE = os.environ.get("INSAR_PREP_SIDE", "1") != "0"         # diagnostic: 0 re-lays the weights out on the main stream
 OUTC_FUSE = os.environ.get("INSAR_OUTC_FUSE", "1") != "0"        # diagnostic: 0 materialises the gradient of outc's input
 WGRAD_FILL_T = float(os.environ.get("INSAR_WGRAD_FILL_T", "0.5"))   # the same for the transposed convs' per-tap weight gradient
 WGRAD_FILL_ALONE = float(os.environ.get("INSAR_WGRAD_FILL_ALONE", "1.0"))   # ... and when it has the GPU to itself
@@ -432,13 +433,17 @@ class ConvBN:
             w = self.conv.weight.detach()
             call("insar_conv3x3_small_fwd", self.x.ref, ptr(w), self.y.ref, ptr(self.stats) if training else 0, s)
         elif self.c64_fwd:
+            self.ctx.join_side()          # GEMM-layout weights come from the side stream (UNetPlan.forward)
             _conv3x3_c64(self.x, self.y, self.w.fwd(), 0, self.stats if training else None)
         elif self.c64:
+            self.ctx.join_side()
             _igemm(self.x, self.y, self.w.fwd(), self.cout, self.x.H, self.x.W, 1, _TAPS3, 0,
                    stats=self.stats if training else None)
         elif self.flat_fwd:
+            self.ctx.join_side()
             _conv3x3_flat(self.x, self.y, self.w.fwd(), 0, self.stats if training else None)
         else:
+            self.ctx.join_side()
             _igemm(self.x, self.y, self.w.fwd(), self.cout, self.x.H, self.x.W, 1, _TAPS3, 0,
                    stats=self.stats if training else None)
         if training and self.stat_rps:
@@ -701,6 +706,7 @@ class UpPlan:
         return [self.mod.weight, self.mod.bias]
 
     def forward(self) -> None:
+        self.ctx.join_side()
         _igemm(self.x, self.out, self.w.fwd(), 4 * self.cout, self.x.H, self.x.W, 1, [(0, 0)], 1,
                bias=self.mod.bias.detach() if self.mod.bias is not None else None)
 
@@ -908,7 +914,14 @@ class UNetPlan:
     def forward(self, x: torch.Tensor, training: bool) -> torch.Tensor:
         s = _lib.stream_ptr
         self.training = training
-        self.weightset.refresh()          # all GEMM-layout weight copies in one launch when the masters moved
+        # all GEMM-layout weight copies in one launch when the masters moved. The first layer works on the fp32
+        # masters, so the re-layout runs on the side stream beside input packing and the first conv / BN / ReLU
+        # passes; the first GEMM conv (ConvBN.forward_conv) joins it.
+        if PREP_SIDE:
+            with self.ctx.side_stream():
+                self.weightset.refresh()
+        else:
+            self.weightset.refresh()
         pack_input(x, self.xin)
         for l in range(5):
             self.enc[l].forward(training)          # levels 0-3 write their max-pool too (pool_out)
