@@ -312,6 +312,13 @@ def _launch_wgrad(d: InsarWgrad, M: int, cin: int, cout: int, ntaps: int, code: 
     call("insar_wgrad", C.byref(d), _lib.stream_ptr())
 
 
+def _side_fill(ctx: "Ctx", bf16_fill: float) -> float:
+    """Share of the work-group slots a side-stream weight gradient aims at. bf16: half (the main stream's kernels are
+    partly HBM- / latency-bound and share the chip well). fp32: all of them — every GEMM there is bound by the fp32
+    matrix rate, nothing complementary runs beside it (config 4: 84.5 vs 85.9 ms/step)."""
+    return bf16_fill if ctx.code == _lib.BF16 else 1.0
+
+
 def _rows_per_part(B: int, H: int) -> int:
     """Image rows folded into one partial-sum row by the row reductions: keep >= ~1024 work-groups in flight
     but hand the per-image fold (one work-group per image) at most 64 rows."""
@@ -584,7 +591,7 @@ def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
         # main stream's kernels keep CUs, there are half as many slabs to fold, and the launch still ends before the
         # next one is due (same-box sweep of the fill factor: 1.0 8.09-8.14, 0.7 7.86, 0.5 7.81-7.86, 0.35 7.86, 0.25
         # 9.26 ms/step). Alone on the GPU (single-stream runs, the per-kernel event pass of bench.py) it fills the chip.
-        fill = WGRAD_FILL if (ctx.side is not None and PROFILER is None) else WGRAD_FILL_ALONE
+        fill = _side_fill(ctx, WGRAD_FILL) if (ctx.side is not None and PROFILER is None) else WGRAD_FILL_ALONE
         nsplit = _wgrad_nsplit(tiles, B * H * W // WG_BKP, 9 * cout * cin, tm, tn, ctx.esize, taps_per_wg=3, fill=fill)
         part = ctx.wgrad_part(nsplit * 9 * cout * cin)
         if PROFILER is not None:
@@ -719,7 +726,7 @@ class UpPlan:
         mpad = tabx.numel()
         tm, tn = _wgrad_tiles(self.cin, self.cout, ctx.code)
         tiles = 4 * (self.cin // tm) * (self.cout // tn)
-        fill = WGRAD_FILL_T if (ctx.side is not None and PROFILER is None) else 1.0
+        fill = _side_fill(ctx, WGRAD_FILL_T) if (ctx.side is not None and PROFILER is None) else 1.0
         nsplit = _wgrad_nsplit(tiles, mpad // WG_BKP, 4 * self.cout * self.cin, tm, tn, ctx.esize, fill=fill)
         def weight_grad():
             with ctx.side_stream():
