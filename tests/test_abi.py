@@ -66,3 +66,26 @@ def test_argument_validation_without_a_gpu():
     assert _lib.call("insar_igemm_num_mtiles", 129, 128) == 2
     assert _lib.call("insar_igemm_tile_rows", 1 << 20, 128) == 256
     assert _lib.call("insar_ce_blocks", 1) == 1
+
+
+def test_tile_selection_queries_without_a_gpu():
+    """The launch-geometry queries are host arithmetic: the rules DESIGN.md states, checked on the layer shapes of the
+    benchmark configuration (B = 16, 256 x 256 tiles)."""
+    F32, BF16 = _lib.F32, _lib.BF16
+    call = _lib.call
+    # per-tap implicit GEMM: 256 x 256 tiles only in bf16, only with N % 256 == 0 and >= 256 such tiles
+    assert call("insar_igemm_tile_cols_dt", 16 * 64 * 64, 256, BF16) == 256          # 64^2 level, 256 M tiles x 1
+    assert call("insar_igemm_tile_cols_dt", 16 * 64 * 64, 256, F32) == 128
+    assert call("insar_igemm_tile_cols_dt", 16 * 32 * 32, 512, BF16) == 128          # 32^2 level: only 128 such tiles
+    assert call("insar_igemm_tile_rows", 16 * 16 * 16, 512) == 256                   # 256 x 64 tiles from half-chip grids on
+    assert call("insar_igemm_tile_cols_dt", 16 * 16 * 16, 512, BF16) == 64
+    # weight gradient: (tile(Cin) << 16) | tile(Cout)
+    pair = lambda ci, co, dt: divmod(call("insar_wgrad_tile_pair", ci, co, dt), 1 << 16)
+    assert pair(1024, 512, BF16) == (256, 256) and pair(256, 128, BF16) == (128, 128) and pair(128, 64, BF16) == (128, 64)
+    assert pair(64, 64, BF16) == (64, 64) and pair(256, 256, F32) == (128, 128) and pair(128, 64, F32) == (64, 64)
+    # row-of-taps kernel: every level of the U-Net (W % 64 == 0, or W = 16 / 32 with whole K steps per image), tiles <= 128
+    act = lambda h, w, c, dt: ctypes.byref(_lib.InsarAct(0, 16, h, w, c, 0, c, dt, 0))
+    rows = lambda h, w, ci, co, dt: divmod(call("insar_wgrad_conv3_tile", act(h, w, ci, dt), co), 1 << 16)
+    assert rows(256, 256, 64, 64, BF16) == (64, 64) and rows(64, 64, 512, 256, BF16) == (128, 128)
+    assert rows(32, 32, 512, 512, BF16) == (128, 128) and rows(16, 16, 1024, 1024, F32) == (128, 128)
+    assert rows(48, 80, 64, 64, BF16) == (0, 0) and rows(3, 16, 64, 64, BF16) == (0, 0)     # per-tap kernel there

@@ -195,3 +195,19 @@ def test_plan_cache_is_bounded():
     assert len(cache.plans) <= cache.MAX_KEYS + 1         # the busy geometry may exceed the cap by one
     assert ("k", 0) in cache.plans and ("k", 7) in cache.plans and ("k", 1) not in cache.plans
     assert cache.get(("k", 7), P) is cache.plans[("k", 7)][0]      # idle plan reused, not rebuilt
+
+
+def test_side_stream_weight_gradients_aim_at_half_the_slots():
+    """Split-K factor of the row-of-taps weight gradient: the cost model is asked for half the work-group slots when the
+    launch runs beside the dgrad chain (engine.WGRAD_FILL), for all of them when it runs alone; fp32 always fills the chip."""
+    from insar_unet_ca_amd import engine, _lib
+    ks = 16 * 256 * 256 // 64
+    full = engine._wgrad_nsplit(3, ks, 9 * 64 * 64, 64, 64, 2, taps_per_wg=3, fill=1.0)
+    half = engine._wgrad_nsplit(3, ks, 9 * 64 * 64, 64, 64, 2, taps_per_wg=3, fill=0.5)
+    assert 0.4 * full <= half <= 0.6 * full
+    assert engine._wgrad_nsplit(192, 64, 9 * 1024 * 1024, 128, 128, 2, taps_per_wg=3, fill=0.5) == 1     # deep layers: no split
+    class C:                     # the only attribute _side_fill reads
+        code = _lib.BF16
+    assert engine._side_fill(C, 0.5) == 0.5
+    C.code = _lib.F32
+    assert engine._side_fill(C, 0.5) == 1.0
