@@ -123,6 +123,8 @@ int insar_conv3x3_flat(const InsarAct* x, const InsarAct* y, const void* w, int3
  * stats: [insar_conv3x3_c64_rows(x)][2][64] BatchNorm partial sums (one row per work-group) or null. */
 int insar_conv3x3_c64_ok(const InsarAct* x, int32_t N);
 int insar_conv3x3_c64_rows(const InsarAct* x);
+/* host-side query of the rolling-window geometry: out[6] = {A, Af, o, R, ntiles, TILE}; 1 if the shape is accepted */
+int insar_conv3x3_c64_geometry(const InsarAct* x, int32_t* out);
 int insar_conv3x3_c64(const InsarAct* x, const InsarAct* y, const void* w, int32_t flip, float* stats,
                       void* stream);
 

@@ -94,6 +94,7 @@ _SIGNATURES = {
     "insar_conv3x3_flat": [_AP, _AP, _P, _I, _P, _P],
     "insar_conv3x3_c64_ok": [_AP, _I],
     "insar_conv3x3_c64_rows": [_AP],
+    "insar_conv3x3_c64_geometry": [_AP, _P],
     "insar_conv3x3_c64": [_AP, _AP, _P, _I, _P, _P],
     "insar_wgrad": [C.POINTER(InsarWgrad), _P],
     "insar_wgrad_tile": [_I, _I],
@@ -177,7 +178,7 @@ def load():
     return lib
 
 
-_COUNT_ONLY = {"insar_igemm_num_mtiles", "insar_igemm_tile_rows", "insar_igemm_tile_cols", "insar_igemm_tile_cols_dt", "insar_wgrad_tile", "insar_wgrad_tile_pair", "insar_wgrad_conv3_tile", "insar_conv3x3_flat_ok", "insar_conv3x3_flat_num_mtiles", "insar_conv3x3_c64_ok", "insar_conv3x3_c64_rows", "insar_conv3x3_small_wgrad_blocks", "insar_conv3x3_small_fwd_rows", "insar_conv1x1_out_bwd_blocks",
+_COUNT_ONLY = {"insar_igemm_num_mtiles", "insar_igemm_tile_rows", "insar_igemm_tile_cols", "insar_igemm_tile_cols_dt", "insar_wgrad_tile", "insar_wgrad_tile_pair", "insar_wgrad_conv3_tile", "insar_conv3x3_flat_ok", "insar_conv3x3_flat_num_mtiles", "insar_conv3x3_c64_ok", "insar_conv3x3_c64_rows", "insar_conv3x3_c64_geometry", "insar_conv3x3_small_wgrad_blocks", "insar_conv3x3_small_fwd_rows", "insar_conv1x1_out_bwd_blocks",
                "insar_ce_blocks"}
 
 

@@ -287,7 +287,11 @@ static bool c64_geometry(const InsarAct& x, C64Args& a) {
   a.A = a.Wp + 1;
   a.Af = (a.A / 64) * 64;
   a.o = a.Af - a.A;
-  a.R = ((2 * C6_TILE + a.Af + a.A + 63) / 64) * 64;
+  // Ring rows: while tile t is computed, its own window [t*TILE + o - A, t*TILE + TILE + Af) is being read AND the
+  // four units of tile t+1, up to t*TILE + 2*TILE + Af, are landing by LDS-DMA: the live span is 2*TILE + Af + A - o
+  // (= 2*TILE + 2*A) pixels. (Round 1 sized it without the -o term: the newest prefetched rows aliased the oldest
+  // rows still being read whenever (W+3) % 64 >= 33; tests/test_host_logic.py walks this geometry for every W.)
+  a.R = ((2 * C6_TILE + a.Af + a.A - a.o + 63) / 64) * 64;
   a.ntiles = (int)((P - a.o + C6_TILE - 1) / C6_TILE);
   return (long long)a.R * C6_ROWB + 8 * 64 * 2 * 4 <= C6_MAX_LDS;
 }
@@ -297,6 +301,15 @@ extern "C" int insar_conv3x3_c64_ok(const InsarAct* x, int32_t N) {
   if (!x || x->dtype != INSAR_BF16 || x->c_len != 64 || N != 64) return 0;
   C64Args a;
   return c64_geometry(*x, a) ? 1 : 0;
+}
+
+// Window geometry of the launch for x (host-side unit tests): out = {A, Af, o, R, ntiles, TILE}. Returns 1 when the
+// kernel accepts the shape, 0 otherwise.
+extern "C" int insar_conv3x3_c64_geometry(const InsarAct* x, int32_t* out) {
+  C64Args a;
+  if (!x || !out || !c64_geometry(*x, a)) return 0;
+  out[0] = a.A; out[1] = a.Af; out[2] = a.o; out[3] = a.R; out[4] = a.ntiles; out[5] = C6_TILE;
+  return 1;
 }
 
 // number of work-groups = rows of the BatchNorm partial-sum slab this launch writes

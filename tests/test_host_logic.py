@@ -211,3 +211,35 @@ def test_side_stream_weight_gradients_aim_at_half_the_slots():
     assert engine._side_fill(C, 0.5) == 0.5
     C.code = _lib.F32
     assert engine._side_fill(C, 0.5) == 1.0
+
+
+def test_c64_ring_never_overwrites_a_live_row():
+    """The persistent 64->64 kernel (csrc/conv3x3_c64.hip) prefetches tile t+1's pixels by LDS-DMA while tile t's
+    taps are still reading the ring: for every image width the newest prefetched pixel must not share a ring row
+    with any pixel of tile t's window. (Round 1 sized the ring 0..A rows short: W % 64 in {32, 48} aliased.)"""
+    import ctypes as C
+    lib = _lib.load()
+    out = (C.c_int32 * 6)()
+    checked = 0
+    for W in list(range(16, 400, 2)):
+        act = _lib.InsarAct(0x1000, 4, 16, W, 64, 0, 64, _lib.BF16, 0)
+        ok = lib.insar_conv3x3_c64_geometry(C.byref(act), out)
+        assert ok == lib.insar_conv3x3_c64_ok(C.byref(act), 64)
+        if not ok:
+            continue
+        A, Af, o, R, ntiles, T = list(out)
+        assert A == W + 3 and Af == (A // 64) * 64 and o == Af - A and R % 64 == 0
+        assert R * 128 + 8 * 64 * 2 * 4 <= 160 * 1024
+        for t0 in (0, 1, 5):
+            first = t0 * T + o - A
+            u0 = (first // 64) * 64                      # floor to a multiple of 64 (python // floors negatives too)
+            for t in range(t0, t0 + 6):
+                lo = t * T + o - A                       # oldest pixel tile t reads
+                hi = t * T + T + Af                      # exclusive end of tile t's window (= its fetch frontier)
+                pre = hi + T                             # frontier after the four units fetched at the top of tile t
+                live = {(p - u0) % R for p in range(lo, hi)}
+                new = {(p - u0) % R for p in range(hi, pre)}
+                assert len(live) == hi - lo, f"W={W}: tile window wraps onto itself (R={R})"
+                assert not (live & new), f"W={W}, tile {t}: {len(live & new)} prefetched rows alias live rows (R={R})"
+        checked += 1
+    assert checked > 100
