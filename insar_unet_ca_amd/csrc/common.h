@@ -134,6 +134,36 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ---- per-device one-time launch setup --------------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of the loaded code object: the flag that
+// remembers "already set" is kept per device (a std::atomic bitmask, one bit per ordinal; devices >= 64 simply set
+// the attribute on every launch) so that a process driving several GPUs, or several host threads, never launches a
+// > 64 KB LDS kernel on a device that has not had the attribute set. One static mask per call site (per kernel).
+#include <atomic>
+static inline int insar_current_device() {
+  int dev = 0;
+  return hipGetDevice(&dev) == hipSuccess ? dev : 0;
+}
+static inline hipError_t insar_set_lds_once(std::atomic<uint64_t>& mask, const void* func, int bytes) {
+  const int dev = insar_current_device();
+  const uint64_t bit = dev < 64 ? (1ull << dev) : 0ull;
+  if (bit && (mask.load(std::memory_order_acquire) & bit)) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && bit) mask.fetch_or(bit, std::memory_order_release);
+  return e;
+}
+// CU count of the current device (cached per ordinal)
+static inline int insar_num_cus() {
+  static std::atomic<int> cache[64];
+  const int dev = insar_current_device();
+  if (dev < 64) { const int c = cache[dev].load(std::memory_order_relaxed); if (c > 0) return c; }
+  hipDeviceProp_t p;
+  int cus = 256;
+  if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) cus = p.multiProcessorCount;
+  if (dev < 64) cache[dev].store(cus, std::memory_order_relaxed);
+  return cus;
+}
+
 static inline int insar_grid_cap(int64_t want, int cap = 2048 * 4) {
   if (want < 1) want = 1;
   return (int)(want > cap ? cap : want);

@@ -265,18 +265,7 @@ __global__ __launch_bounds__(C6_THREADS, 1) void conv3x3_c64_kernel(C64Args a) {
 }
 
 // ---- host side -----------------------------------------------------------------------------------
-static int c64_num_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
-      cus = p.multiProcessorCount;
-    else
-      cus = 256;
-  }
-  return cus;
-}
+static int c64_num_cus() { return insar_num_cus(); }
 
 static bool c64_geometry(const InsarAct& x, C64Args& a) {
   const long long P = (long long)x.B * (x.H + 2) * (x.W + 2);
@@ -338,11 +327,10 @@ extern "C" int insar_conv3x3_c64(const InsarAct* x, const InsarAct* y, const voi
   a.Cx = x->C; a.cx_off = x->c_off; a.Cy = y->C; a.cy_off = y->c_off; a.N = 64;
   a.flip = flip ? 1 : 0;
   const int lds = a.R * C6_ROWB + 8 * 64 * 2 * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, C6_MAX_LDS);
+  static std::atomic<uint64_t> attr_mask{0};     // per-device, see common.h
+  {
+    hipError_t e = insar_set_lds_once(attr_mask, (const void*)conv3x3_c64_kernel<2>, C6_MAX_LDS);
     if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_conv3x3_c64: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
   }
   const int cus = c64_num_cus();
   const int grid = a.ntiles < cus ? a.ntiles : cus;

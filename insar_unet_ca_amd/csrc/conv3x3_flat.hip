@@ -302,11 +302,10 @@ extern "C" int insar_conv3x3_flat_num_mtiles(const InsarAct* x) { return x ? fla
 template <typename T, int BN>
 static int launch_flat(FlatArgs& a, hipStream_t s) {
   using Cfg = FlatCfg<T, BN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_flat_kernel<T, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+  static std::atomic<uint64_t> attr_mask{0};     // per-device, see common.h
+  {
+    hipError_t e = insar_set_lds_once(attr_mask, (const void*)conv3x3_flat_kernel<T, BN>, Cfg::LDS_BYTES);
     if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_conv3x3_flat: hipFuncSetAttribute(%d bytes LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
-    attr_set = true;
   }
   a.num_ntiles = a.N / BN;
   const long long grid = (long long)a.num_mtiles * a.num_ntiles;

@@ -325,11 +325,10 @@ extern "C" int insar_igemm_num_mtiles(int64_t M, int32_t N) {
 template <typename T, int BM, int BN, int NSTAGE>
 static int launch_igemm(IgemmArgs& a, hipStream_t s) {
   using Cfg = IgemmCfg<T, BM, BN, NSTAGE>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+  static std::atomic<uint64_t> attr_mask{0};     // per-device, see common.h
+  {
+    hipError_t e = insar_set_lds_once(attr_mask, (const void*)igemm_kernel<T, BM, BN, NSTAGE>, Cfg::LDS_BYTES);
     if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_igemm: hipFuncSetAttribute(%d bytes LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
-    attr_set = true;
   }
   a.num_mtiles = (int)((a.M + BM - 1) / BM);
   a.num_ntiles = a.N / BN;

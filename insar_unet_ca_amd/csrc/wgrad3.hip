@@ -250,11 +250,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad3_kernel(Wgra
 template <typename T, int TM, int TN, int NW>
 static int launch_wgrad3(Wgrad3Args& a, hipStream_t s) {
   using Cfg = Wgrad3Cfg<T, TM, TN, NW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad3_kernel<T, TM, TN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+  static std::atomic<uint64_t> attr_mask{0};     // per-device, see common.h
+  {
+    hipError_t e = insar_set_lds_once(attr_mask, (const void*)wgrad3_kernel<T, TM, TN, NW>, Cfg::LDS_BYTES);
     if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_wgrad_conv3: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
   }
   a.mtc = a.Cin / TM; a.ntc = a.Cout / TN;
   const long long grid = (long long)a.nsplit * 3 * a.mtc * a.ntc;

@@ -352,15 +352,33 @@ def _wgrad_nsplit(tiles: int, ksteps: int, slab_floats: int = 0, tm: int = 128, 
     return best
 
 
+GROUP_ALIGN = 64        # elements: every backward stage of the flat buffers ends on a multiple of this, so that any
+                        # union of stages (a DP bucket) splits into <= 16 equal, 16-byte aligned rank shards
+
+
+def flat_layout(groups: List[List[torch.nn.Parameter]]):
+    """Offsets of the parameters inside a flat fp32 buffer: 16-byte aligned views in the given order, each group
+    (= backward stage) padded to GROUP_ALIGN elements. Returns (offsets per parameter in order, padded group sizes,
+    total)."""
+    offs, sizes, total = [], [], 0
+    for g in groups:
+        begin = total
+        for p in g:
+            offs.append(total)
+            total += _round_up(p.numel(), 4)
+        total = _round_up(total, GROUP_ALIGN)
+        sizes.append(total - begin)
+    return offs, sizes, total
+
+
 class GradSink:
     """Flat fp32 gradient buffer: one 16-byte-aligned view per parameter, in backward order."""
 
-    def __init__(self, ctx: Ctx, params: List[torch.nn.Parameter]):
-        self.params = list(params)
-        offs, total = [], 0
-        for p in self.params:
-            offs.append(total)
-            total += _round_up(p.numel(), 4)
+    def __init__(self, ctx: Ctx, params, groups: Optional[List[List[torch.nn.Parameter]]] = None):
+        if groups is None:
+            groups = [list(params)]
+        self.params = [p for g in groups for p in g]
+        offs, self.group_sizes, total = flat_layout(groups)
         self.flats = [torch.zeros(total, dtype=torch.float32, device=ctx.device) for _ in range(2)]
         self.views = [{id(p): f[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, offs)} for f in self.flats]
         self.active = 0
@@ -379,6 +397,29 @@ class GradSink:
 
     def flat(self) -> torch.Tensor:
         return self.flats[self.active]
+
+
+def double_conv_params(mod) -> List[torch.nn.Parameter]:
+    seq = mod.double_conv
+    ps = [seq[0].weight, seq[0].bias, seq[1].weight, seq[1].bias,
+          seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias]
+    if len(seq) > 6:
+        ps += [seq[6].fc[0].weight, seq[6].fc[2].weight]
+    return ps
+
+
+def grad_groups(net) -> List[List[torch.nn.Parameter]]:
+    """Parameters of a UNet grouped by the backward stage that completes their gradients, in completion order
+    (the layout of the flat gradient buffer, of the DP buckets and of the sharded optimizer's parameter buffer)."""
+    ups = [net.up1, net.up2, net.up3, net.up4]
+    convs = [net.conv1, net.conv2, net.conv3, net.conv4]
+    encs = [net.inc, net.down1[1], net.down2[1], net.down3[1], net.down4[1]]
+    groups = [[net.outc.weight, net.outc.bias] + double_conv_params(convs[3]) + [ups[3].weight, ups[3].bias]]
+    for i in (2, 1, 0):
+        groups.append(double_conv_params(convs[i]) + [ups[i].weight, ups[i].bias])
+    for l in (4, 3, 2, 1, 0):
+        groups.append(double_conv_params(encs[l]))
+    return groups
 
 
 class ConvBN:
@@ -654,12 +695,7 @@ class DoubleConvPlan:
         self.dz1 = None
 
     def params(self) -> List[torch.nn.Parameter]:
-        seq = self.mod.double_conv
-        ps = [seq[0].weight, seq[0].bias, seq[1].weight, seq[1].bias,
-              seq[3].weight, seq[3].bias, seq[4].weight, seq[4].bias]
-        if self.se:
-            ps += [self.se.fc1.weight, self.se.fc2.weight]
-        return ps
+        return double_conv_params(self.mod)
 
     def forward(self, training: bool, outc: Optional["OutConvPlan"] = None) -> Optional[torch.Tensor]:
         """outc: the 1x1 output conv when this is the last block and its output goes nowhere else — the final
@@ -885,31 +921,20 @@ class UNetPlan:
             self.up.append(UpPlan(ctx, ups[i], src, self.cat[l].slice(widths[l], widths[l]), f"up{i + 1}"))
             self.dconv.append(DoubleConvPlan(ctx, convs[i], self.cat[l], self.dec[l], f"conv{i + 1}"))
         self.outc = OutConvPlan(ctx, net.outc, self.dec[0])
-        # parameters in the order their gradients complete during backward
-        order: List[torch.nn.Parameter] = []
-        order += self.outc.params()
-        for i in (3, 2, 1, 0):
-            order += self.dconv[i].params() + self.up[i].params()
-        for l in (4, 3, 2, 1, 0):
-            order += self.enc[l].params()
-        self.grad_params = order
-        self.sink = GradSink(ctx, order)
+        # parameters in the order their gradients complete during backward, grouped by backward stage
+        groups = grad_groups(net)
+        self.grad_params = [p for g in groups for p in g]
+        self.sink = GradSink(ctx, None, groups)
         # flat-buffer offsets at which each backward stage's gradients are complete (for DP buckets)
-        stage_sizes = []
-        first = self.outc.params() + self.dconv[3].params() + self.up[3].params()
-        stage_sizes.append(sum(_round_up(p.numel(), 4) for p in first))
-        for i in (2, 1, 0):
-            stage_sizes.append(sum(_round_up(p.numel(), 4) for p in self.dconv[i].params() + self.up[i].params()))
-        for l in (4, 3, 2, 1, 0):
-            stage_sizes.append(sum(_round_up(p.numel(), 4) for p in self.enc[l].params()))
-        self.stage_sizes = stage_sizes
-        self.stage_ends = [sum(stage_sizes[:i + 1]) for i in range(len(stage_sizes))]
+        self.stage_sizes = self.sink.group_sizes
+        self.stage_ends = [sum(self.stage_sizes[:i + 1]) for i in range(len(self.stage_sizes))]
         self._closes = {}
         self.busy = False
         self.training = True
         gws = [b.u1.w for b in self.enc + self.dconv if b.u1.w is not None] + [b.u2.w for b in self.enc + self.dconv]
         gws += [u.w for u in self.up]
         self.weightset = WeightSet(ctx, gws)
+        self.bn_modules = [u.bn for b in self.enc + self.dconv for u in (b.u1, b.u2)]
 
     def bucket_closes(self, min_elems: int):
         if min_elems not in self._closes:

@@ -403,6 +403,11 @@ class MaxPool2d(nn.MaxPool2d):
 class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, training, track, hooks, x, *params):
+        if x.requires_grad:
+            # nn.Module semantics would return d(loss)/d(input); the first layer's input gradient is not part of the
+            # hot path (the reference never asks for it: images come from the loader). Say so instead of returning None.
+            raise _lib.InsarError("UNet: the gradient with respect to the input tensor is not provided by the HIP path; "
+                                  "pass the images with requires_grad=False")
         logits = plan.forward(x, training)
         ctx.plan, ctx.hooks = plan, hooks
         ctx.lease = _Lease(plan) if track else None
@@ -411,21 +416,31 @@ class _UNetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         plan = ctx.plan
-        grads = plan.backward(dlogits, on_bucket=ctx.hooks.get("on_bucket") if ctx.hooks else None)
-        if ctx.hooks and ctx.hooks.get("on_done"):
-            ctx.hooks["on_done"](plan)
+        hooks = ctx.hooks or {}
+        if hooks.get("on_begin"):
+            hooks["on_begin"](plan)
+        grads = plan.backward(dlogits, on_bucket=hooks.get("on_bucket"))
+        if hooks.get("on_done"):
+            hooks["on_done"](plan)
         if ctx.lease:
             ctx.lease.release()
-        if ctx.hooks is not None and ctx.hooks.get("direct_grad", True):
+        needs = ctx.needs_input_grad[5:]
+        mode = hooks.get("grad_mode", "direct" if hooks.get("direct_grad", True) else "autograd") if ctx.hooks is not None else "autograd"
+        if mode == "none":          # sharded optimizer: the reduced gradients live in its shards, p.grad stays None
+            return (None,) * (5 + len(grads))
+        if mode == "direct":
             # Hand the flat-buffer views to the parameters ourselves (what AccumulateGrad would do,
             # minus one 125 MB clone per step): first gradient -> alias the view, otherwise add.
-            for p, g in zip(plan.grad_params, grads):
+            # Frozen parameters (requires_grad=False) get no .grad, as with AccumulateGrad.
+            for p, g, need in zip(plan.grad_params, grads, needs):
+                if not need:
+                    continue
                 if p.grad is None:
                     p.grad = g
                 else:
                     p.grad.add_(g)
             return (None,) * (5 + len(grads))
-        return (None, None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None) + tuple(g if need else None for g, need in zip(grads, needs))
 
 
 class UNet(nn.Module):
@@ -471,6 +486,12 @@ class UNet(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         _require_device(x, "UNet")
         plan = self._plan(x)
+        # BatchNorm mode is a per-layer flag in nn.Module; the plan runs the whole net in one mode. A frozen encoder
+        # (`net.down1.eval()` under `net.train()`) would silently be ignored: refuse it.
+        for bn in plan.bn_modules:
+            if bn.training != self.training:
+                raise _lib.InsarError("UNet: mixed BatchNorm modes (a sub-module's .training differs from the net's) "
+                                      "are not supported by the HIP path; call net.train() / net.eval() on the whole net")
         return _UNetFn.apply(plan, self.training, torch.is_grad_enabled(), self._hooks, x, *plan.grad_params)
 
     def _apply(self, fn, *args, **kwargs):

@@ -73,3 +73,187 @@ def test_bucketed_allreduce_equals_mean_of_shard_oracle_grads(golden, tmp_path):
             assert float(v.abs().max()) < 1e-6
             continue
         check_summary(g9, f"mean_grad/{k}", v, 2e-4)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# world 8: sampler + bucket plan + reducer on the engine's real flat-buffer layout
+# ------------------------------------------------------------------------------------------------------------
+class _FakeCtx:
+    """engine.Ctx's stream interface on a host without a GPU (everything runs in order on the CPU)."""
+
+    def side_stream(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def join_side(self):
+        pass
+
+
+class _FakeSink:
+    def __init__(self, flat):
+        self._flat = flat
+
+    def flat(self):
+        return self._flat
+
+
+class _FakePlan:
+    """What DataParallel's hooks read from an engine.UNetPlan: the stage layout of the flat gradient buffer."""
+
+    def __init__(self, net, flat):
+        from insar_unet_ca_amd import engine
+        from insar_unet_ca_amd.parallel import plan_buckets
+        self.groups = engine.grad_groups(net)
+        self.offs, self.stage_sizes, self.total = engine.flat_layout(self.groups)
+        self.stage_ends = list(np.cumsum(self.stage_sizes))
+        self.ctx, self.sink = _FakeCtx(), _FakeSink(flat)
+        self._pb = plan_buckets
+
+    def bucket_closes(self, min_elems):
+        return set(self._pb(self.stage_sizes, min_elems))
+
+
+def _run_backward_hooks(net, plan):
+    """The call sequence of modules._UNetFn.backward around engine.UNetPlan.backward (9 stages)."""
+    h = net._hooks
+    h["on_begin"](plan)
+    for stage in range(len(plan.stage_sizes)):
+        h["on_bucket"](plan, ("stage", stage))
+    h["on_done"](plan)
+
+
+def _cpu_adam_rows(rows, lr, b1, b2, eps, bc1, bc2_sqrt):
+    """Element-wise Adam with the kernel's formula (csrc/loss_optim.hip adam_kernel = torch.optim.Adam, :466): test
+    stand-in for the HIP launch so the EXCHANGE logic of both schemes can run under gloo on a host without a GPU."""
+    for p, g, m, v in rows:
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        p.addcdiv_(m, v.sqrt().div_(bc2_sqrt).add_(eps), value=-lr / bc1)
+
+
+def _worker8(rank: int, world: int, port: int, out_dir: str):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd import engine
+    from insar_unet_ca_amd.data import ShardedSampler, SyntheticTiles
+    from insar_unet_ca_amd.parallel import DataParallel
+    from oracle import closed_form as cf
+    from oracle import unet_ca_oracle as orc
+
+    torch.manual_seed(1000 + rank)                         # different init per rank: the wrapper's broadcast fixes it
+    net = iu.UNet(2, 2, True)
+    dp = DataParallel(net, bucket_mb=8.0)
+    sd = OrderedDict((k, v.detach().clone()) for k, v in net.state_dict().items())
+    # this rank's tiles: ShardedSampler deals the 16-tile global batch round-robin (rank r takes r::8)
+    ds = SyntheticTiles(16, 16, offset=4000)
+    idx = list(ShardedSampler(len(ds), rank, world, shuffle=False))
+    assert idx == list(range(rank, 16, world))
+    x = torch.stack([ds[i][0] for i in idx])
+    y = torch.stack([ds[i][1] for i in idx])
+    names = [k for k in sd if orc.is_param(k)]
+    work = OrderedDict(sd)
+    for k in names:
+        work[k] = sd[k].clone().requires_grad_(True)
+    loss = orc.cross_entropy(orc.unet_forward(work, x, True, True), y)
+    grads = dict(zip(names, torch.autograd.grad(loss, [work[k] for k in names])))
+    # lay the local gradients out exactly as engine.GradSink does, then run the wrapper's backward hooks
+    by_param = {id(p): k for k, p in net.named_parameters()}
+    plan = _FakePlan(net, None)
+    flat = torch.zeros(plan.total)
+    for p, o in zip([q for g in plan.groups for q in g], plan.offs):
+        flat[o:o + p.numel()] = grads[by_param[id(p)]].reshape(-1)
+    local = flat.clone()
+    plan.sink = _FakeSink(flat)
+    _run_backward_hooks(net, plan)
+    # expected mean from a strided sample of every rank's LOCAL buffer (1/97 of 31 M elements: the gather stays small);
+    # it walks every parameter tensor and the padding between stages
+    sample = local[::97].contiguous()
+    gathered = [torch.zeros_like(sample) for _ in range(world)] if rank == 0 else None
+    dist.gather(sample, gathered, dst=0)
+    if rank == 0:
+        mean = torch.stack(gathered).double().mean(0)
+        torch.save({"reduced": flat[::97].clone(), "mean": mean, "buckets": len(plan.bucket_closes(dp.min_elems))},
+                   os.path.join(out_dir, "w8.pt"))
+    # every rank ends with the same buffer: compare checksums
+    chk = torch.tensor([float(flat.double().sum()), float(flat[::1013].double().abs().sum())], dtype=torch.float64)
+    allchk = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(allchk, chk)
+    assert all(torch.equal(c, allchk[0]) for c in allchk)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world8_bucketed_allreduce_on_the_engine_layout(tmp_path):
+    """8 ranks (gloo): parameters broadcast from rank 0, tiles dealt by ShardedSampler, each rank's ORACLE gradients
+    laid out as engine.GradSink does, exchanged by DataParallel's own hooks in >= 8 MiB buckets: every rank must end
+    with the mean of the 8 shard gradients (SURVEY 8e's DP parity oracle), also in the padding between stages."""
+    port = 31000 + (os.getpid() % 2000)
+    mp.spawn(_worker8, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    r = torch.load(tmp_path / "w8.pt")
+    assert r["buckets"] >= 3
+    scale = float(r["mean"].abs().max())
+    assert scale > 0
+    assert float((r["reduced"].double() - r["mean"]).abs().max()) <= 2e-6 * scale
+
+
+# ------------------------------------------------------------------------------------------------------------
+# world 2: reduce-scatter + sharded Adam + all-gather == all-reduce + Adam, bit for bit
+# ------------------------------------------------------------------------------------------------------------
+def _worker_sharded(rank: int, world: int, port: int, out_dir: str):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd.parallel import DataParallel, ShardedAdam
+
+    def run(shard: bool):
+        torch.manual_seed(5)
+        net = iu.UNet(2, 2, True)
+        dp = DataParallel(net, bucket_mb=8.0, shard_optimizer=shard)
+        plan = _FakePlan(net, None)
+        params = [q for g in plan.groups for q in g]
+        m = torch.zeros(plan.total)
+        v = torch.zeros(plan.total)
+        opt = ShardedAdam(dp, lr=1e-3, kernel=_cpu_adam_rows) if shard else None
+        for step in range(3):
+            gen = torch.Generator().manual_seed(77 * step + rank)
+            flat = torch.randn(plan.total, generator=gen) * 1e-2
+            plan.sink = _FakeSink(flat)
+            _run_backward_hooks(net, plan)
+            if shard:
+                opt.step()
+            else:           # the same arithmetic on every element of every parameter, as optim.Adam does
+                b1, b2, t = 0.9, 0.999, step + 1
+                rows = [(p.data.view(-1), flat[o:o + p.numel()], m[o:o + p.numel()], v[o:o + p.numel()])
+                        for p, o in zip(params, plan.offs)]
+                _cpu_adam_rows(rows, 1e-3, b1, b2, 1e-8, 1 - b1 ** t, (1 - b2 ** t) ** 0.5)
+        return OrderedDict((k, p.detach().clone()) for k, p in net.named_parameters()), dp
+
+    plain, _ = run(False)
+    sharded, dp = run(True)
+    assert all(p.grad is None for p in dp.module.parameters())
+    # state_dict still has the reference's 154 keys and the parameters are views of the flat buffer
+    assert len(dp.module.state_dict()) == 154
+    base, n = dp.flat_p.data_ptr(), dp.flat_p.numel() * 4
+    assert all(base <= p.data_ptr() < base + n for p in dp.module.parameters())
+    same = all(torch.equal(plain[k], sharded[k]) for k in plain)
+    moved = any(not torch.equal(plain[k], torch.zeros_like(plain[k])) for k in plain)
+    torch.save({"same": same, "moved": moved, "w": sharded["outc.weight"], "shard_elems": sum(t.numel() for t in dp.sharded.p),
+                "total": dp.flat_p.numel()}, os.path.join(out_dir, f"sh{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_adam_equals_allreduce_adam_bitwise(tmp_path):
+    port = 33000 + (os.getpid() % 2000)
+    mp.spawn(_worker_sharded, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "sh0.pt"), torch.load(tmp_path / "sh1.pt")
+    assert r0["same"] and r1["same"] and r0["moved"]
+    assert torch.equal(r0["w"], r1["w"])
+    assert r0["shard_elems"] * 2 == r0["total"]           # each rank holds (and updates) half of the optimizer state
