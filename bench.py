@@ -23,14 +23,17 @@ if ROOT not in sys.path:
 
 # --- algorithmic figures (SURVEY §8d / BASELINE.md) ------------------------------------------------
 FLOP_PER_TILE_256 = 288.7e9           # forward + backward, 2x256x256 tile
-BYTES_PER_TILE_BF16_B16 = 825e6       # ideal-fusion HBM traffic per tile at B=16 (bf16 activations)
 PEAK_BF16_TFLOPS = 2500.0             # dense MFMA peak, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3               # fp32 MFMA = fp32 vector rate
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(batch: int = 8, size: int = 256):
-    """The oracle (CPU restatement of the reference's training step, fp32, torch/oneDNN) timed on the
-    host cores of this box: one untimed + one timed step on a bounded sample."""
+def cpu_baseline(size: int = 256):
+    """the oracle (CPU restatement of the reference, fp32, torch/oneDNN; pinned to the reference by
+    tests/golden) timed on the host cores of this box, on a bounded sample:
+      * config 1: eval-mode forward latency of one [1,2,256,256] tile (3 warm-up + 10 timed);
+      * the training step of Unet-ChannalAttention.py:342-346 on [4,2,256,256]: CE + Adam(lr=1e-4), 1 warm-up + 3 timed.
+    `value` is the training figure (the metric's unit, tiles/s)."""
     from collections import OrderedDict
 
     from insar_unet_ca_amd.data import make_batch
@@ -46,17 +49,28 @@ def cpu_baseline(batch: int = 8, size: int = 256):
     import insar_unet_ca_amd as iu
 
     sd = OrderedDict((k, v.clone()) for k, v in iu.UNet(2, 2, True).state_dict().items())
+    x1, _ = make_batch(0, 1, size)
+    with torch.no_grad():
+        for _ in range(3):
+            orc.unet_forward(sd, x1, use_se=True, training=False)
+        t0 = time.time()
+        for _ in range(10):
+            orc.unet_forward(sd, x1, use_se=True, training=False)
+        fwd_ms = 1e3 * (time.time() - t0) / 10
+    batch = 4
     x, y = make_batch(0, batch, size)
     state = {}
-    orc.train_step(sd, state, x, y, use_se=True, lr=1e-4, dice_weight=1.0)      # warm-up (primitive creation)
+    orc.train_step(sd, state, x, y, use_se=True, lr=1e-4)      # warm-up (primitive creation)
     nsteps = 3
     t0 = time.time()
     for _ in range(nsteps):
-        orc.train_step(sd, state, x, y, use_se=True, lr=1e-4, dice_weight=1.0)
+        orc.train_step(sd, state, x, y, use_se=True, lr=1e-4)
     dt = time.time() - t0
     return {"value": nsteps * batch / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": f"{nsteps} timed fp32 train steps (fwd+Dice/CE+bwd+Adam) of the CPU oracle on {batch} synthetic "
-                      f"{size}x{size}x2 tiles each, torch {torch.__version__} CPU, {cores} threads; {dt:.2f} s"}
+            "eval_forward_ms_1x2x256x256": round(fwd_ms, 1), "eval_forward_tiles_per_s": round(1e3 / fwd_ms, 2),
+            "sample": f"{nsteps} timed fp32 train steps (fwd + CE + bwd + Adam, Unet-ChannalAttention.py:342-346) of the CPU "
+                      f"oracle on {batch} synthetic {size}x{size}x2 tiles each ({dt:.2f} s), and 10 timed eval forwards of one "
+                      f"tile (config 1); torch {torch.__version__} CPU/oneDNN, {cores} threads"}
 
 
 def main() -> int:
@@ -69,6 +83,8 @@ def main() -> int:
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--loss", default="dice_ce", choices=["dice_ce", "ce"])
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--shard-optimizer", action="store_true",
+                    help="N > 1: reduce-scatter + Adam on the 1/N shard + all-gather instead of all-reduce + full Adam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -79,7 +95,12 @@ def main() -> int:
     if world != args.gpus and world > 1:
         print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
     ndev = torch.cuda.device_count()
-    local_rank = local_rank % max(ndev, 1)          # rehearsal: several ranks may share the one visible GPU
+    if world > ndev and args.backend == "nccl":
+        # one process per GPU over RCCL: folding ranks onto one device would silently measure something else
+        print(f"error: WORLD_SIZE={world} but only {ndev} GPU(s) visible; RCCL needs one device per rank "
+              "(use --backend gloo for a functional rehearsal on fewer GPUs)", file=sys.stderr)
+        return 2
+    local_rank = local_rank % max(ndev, 1)          # gloo rehearsal only: several ranks may share the one visible GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -101,9 +122,13 @@ def main() -> int:
     model = net
     if world > 1:
         from insar_unet_ca_amd.parallel import DataParallel
-        model = DataParallel(net)
+        model = DataParallel(net, shard_optimizer=args.shard_optimizer)
     crit = iu.DiceCELoss(ignore_index=255) if args.loss == "dice_ce" else iu.CrossEntropyLoss(ignore_index=255)
-    opt = iu.Adam(net.parameters(), lr=1e-4)
+    if world > 1 and args.shard_optimizer:
+        from insar_unet_ca_amd.parallel import ShardedAdam
+        opt = ShardedAdam(model, lr=1e-4)
+    else:
+        opt = iu.Adam(net.parameters(), lr=1e-4)
 
     # synthetic tiles, resident in HBM before timing; every rank draws different tiles
     nb = 2
@@ -140,25 +165,24 @@ def main() -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # Roofline leg: the same K steps again, in the same process, with a HIP-event pair around every
-    # GEMM-class launch (recorded on the stream the kernels run on). Kept out of the timed region above
-    # because ~130 event records per step cost ~2.5 ms/step (they serialise the queue).
-    timer = None
-    timed_elapsed = None
-    if not args.no_kernel_timing and rank == 0:
-        timer = engine.KernelTimer()
-        engine.PROFILER = timer
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            step(i)
-        torch.cuda.synchronize()
-        timed_elapsed = time.perf_counter() - t1
-        engine.PROFILER = None
-    elif not args.no_kernel_timing:
-        for i in range(args.steps):         # keep the other ranks in lock-step with rank 0's extra pass
-            step(i)
-        torch.cuda.synchronize()
+    # Roofline leg: the same K steps twice more, in the same process, with a HIP-event pair around every GEMM-class
+    # launch, recorded on the stream the kernel is launched on (main or side). Pass 1 keeps the launch configuration
+    # of the timed region (weight gradients on the side stream beside the dgrad chain, split-K for half the slots);
+    # pass 2 runs everything on ONE stream (each kernel alone on the chip, split-K that fills it). Both are kept out
+    # of the timed region above because ~130 event records per step cost host time and perturb the overlap.
+    timers = {}
+    if not args.no_kernel_timing:
+        for mode in ("timed_config", "alone"):
+            timer = engine.KernelTimer(alone=(mode == "alone"))
+            engine.PROFILER = timer
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                step(i)
+            torch.cuda.synchronize()
+            timer.elapsed = time.perf_counter() - t1
+            engine.PROFILER = None
+            timers[mode] = timer
     final_loss = float(loss.detach())
 
     if rank == 0:
@@ -177,45 +201,74 @@ def main() -> int:
             "final_loss": round(final_loss, 5),
             "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 3),
             "hbm_allocated_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
-            "frac_of_mfma_roofline": round(per_gpu * FLOP_PER_TILE_256 * (args.size / 256) ** 2 / (PEAK_BF16_TFLOPS * 1e12), 4),
-            "frac_of_hbm_roofline": round(per_gpu * BYTES_PER_TILE_BF16_B16 * (args.size / 256) ** 2 / (PEAK_HBM_GBS * 1e9), 4),
         }
-        if timer is not None:
-            summ = timer.summary()
+        sz = (args.size / 256) ** 2
+        if args.dtype == "bf16":
+            peak, bytes_tile = PEAK_BF16_TFLOPS, (754e6 * sz + 1125e6 / args.batch)
+        else:
+            peak, bytes_tile = PEAK_F32_TFLOPS, (1508e6 * sz + 1250e6 / args.batch)
+        fl = per_gpu * FLOP_PER_TILE_256 * sz / 1e12
+        bw = per_gpu * bytes_tile / 1e9
+        out["frac_of_mfma_roofline"] = round(fl / peak, 4)
+        out["frac_of_hbm_roofline"] = round(bw / PEAK_HBM_GBS, 4)
+        bound = "mfma" if fl / peak >= bw / PEAK_HBM_GBS else "hbm"
+        out["roofline_step"] = {"bound": bound, "achieved": round(fl if bound == "mfma" else bw, 2),
+                                "peak": peak if bound == "mfma" else PEAK_HBM_GBS, "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                                "frac": round(max(fl / peak, bw / PEAK_HBM_GBS), 4),
+                                "algorithmic": f"{FLOP_PER_TILE_256 * sz / 1e9:.1f} GFLOP and {bytes_tile / 1e6:.0f} MB per tile "
+                                               "(SURVEY 8d), whole step incl. loss and Adam, timed region"}
+        if timers:
+            summ = timers["timed_config"].summary()
+            alone = timers["alone"].summary()
+            t_el = timers["timed_config"].elapsed
             dom_tag = max(summ, key=lambda k: summ[k]["ms"]) if summ else None
             if dom_tag:
                 dom = summ[dom_tag]
-                peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
-                traffic = None
-                tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-                if os.path.isfile(tpath):
+                traffic, tfile = None, None
+                import glob
+                for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
                     try:
                         traffic = json.load(open(tpath)).get(dom_tag, {}).get("hbm_bytes_per_launch")
                     except Exception:
                         traffic = None
+                    if traffic is not None:
+                        tfile = os.path.relpath(tpath, ROOT)
+                        break
+                al = alone.get(dom_tag)
                 out["roofline"] = {
                     "kernel": dom_tag, "bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": traffic,
                     "flop_per_launch": round(dom["flops"] / dom["launches"], 1),
                     "algorithmic_bytes_per_launch": round(dom.get("bytes", 0.0) / dom["launches"], 1) or None,
                     "avg_launch_us": round(dom["avg_us"], 2), "launches": dom["launches"],
-                    "share_of_step": round(dom["ms"] / (1e3 * timed_elapsed), 4),
-                    "measured": "HIP events around each launch on the launch stream, in a second pass of the same %d "
-                                "steps run on ONE stream (as with INSAR_SIDE_STREAM=0: per-kernel durations without "
-                                "the weight-gradient overlap, weight gradients with the split-K factor that fills "
-                                "the chip; in the timed region they run beside the dgrad chain on half the slots; "
-                                "%.2f ms/step with events vs %.2f ms/step in the timed "
-                                "region); compare profiles/r01_bench_kernel_stats_single_stream.csv; traffic = "
-                                "rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per launch from profiles/r01_pmc_traffic.json" %
-                                (args.steps, 1e3 * timed_elapsed / args.steps, ms),
+                    "share_of_step": round(dom["ms"] / (1e3 * t_el), 4),
+                    "alone": ({"achieved": round(al["tflops"], 2), "frac": round(al["tflops"] / peak, 4),
+                               "avg_launch_us": round(al["avg_us"], 2)} if al else None),
+                    "measured": "HIP events around each launch on the stream it is launched on, in a second pass of the "
+                                "same %d steps in the launch configuration of the timed region (weight gradients on the "
+                                "side stream beside the dgrad chain, split-K for half the work-group slots: kernels that "
+                                "overlap share the chip, so their durations are longer than alone; %.2f ms/step with "
+                                "events vs %.2f ms/step timed); `alone` = a third pass on ONE stream, every kernel by "
+                                "itself on the chip (%.2f ms/step); compare profiles/ kernel stats; traffic = rocprofv3 "
+                                "PMC (2*FETCH_SIZE + WRITE_SIZE) per launch from %s" %
+                                (args.steps, 1e3 * t_el / args.steps, ms,
+                                 1e3 * timers["alone"].elapsed / args.steps, tfile or "profiles/ (none found)"),
                 }
-            gemm_ms = sum(v["ms"] for v in summ.values())
-            gemm_fl = sum(v["flops"] for v in summ.values())
-            out["gemm_kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
-                                       "tflops": round(v["tflops"], 2), "share_of_step": round(v["ms"] / (1e3 * timed_elapsed), 4)}
-                                   for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
-            out["gemm_total"] = {"tflops": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 2),
-                                 "share_of_step": round(gemm_ms / (1e3 * timed_elapsed), 4)}
+
+            def table(sm, el):
+                return {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "tflops": round(v["tflops"], 2),
+                            "share_of_step": round(v["ms"] / (1e3 * el), 4)}
+                        for k, v in sorted(sm.items(), key=lambda kv: -kv[1]["ms"])}
+
+            def total(sm, el):
+                gm, gf = sum(v["ms"] for v in sm.values()), sum(v["flops"] for v in sm.values())
+                return {"tflops": round(gf / (gm * 1e-3) / 1e12, 2) if gm > 0 else 0.0, "ms_per_step": round(gm / args.steps, 3),
+                        "share_of_step": round(gm / (1e3 * el), 4)}
+
+            out["gemm_kernels"] = table(summ, t_el)
+            out["gemm_total"] = total(summ, t_el)
+            out["gemm_kernels_alone"] = table(alone, timers["alone"].elapsed)
+            out["gemm_total_alone"] = total(alone, timers["alone"].elapsed)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

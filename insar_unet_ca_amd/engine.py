@@ -85,7 +85,7 @@ class Ctx:
     def side_stream(self):
         """Run the enclosed launches on the side stream, ordered after everything enqueued so far on the
         current stream. Per-kernel timing passes (PROFILER) stay on one stream."""
-        if self.side is None or PROFILER is not None:
+        if self.side is None or (PROFILER is not None and PROFILER.alone):
             yield
             return
         self.side.wait_stream(torch.cuda.current_stream())
@@ -213,7 +213,12 @@ class KernelTimer:
     """Optional HIP-event timing of the GEMM-class launches (bench.py's roofline leg). Events are
     recorded on torch's current stream, which is the stream the kernels are launched on."""
 
-    def __init__(self):
+    def __init__(self, alone: bool = True):
+        # alone: every launch on ONE stream (no weight-gradient overlap, split-K that fills the chip): per-kernel
+        # durations. Otherwise the launch configuration of an ordinary step is kept (side stream, half-chip split-K)
+        # and the events of a side-stream kernel are recorded on the side stream.
+        self.alone = alone
+        self.elapsed = 0.0
         self.records: Dict[str, list] = {}
 
     def run(self, tag: str, flops: float, fn, nbytes: float = 0.0) -> None:
@@ -632,7 +637,7 @@ def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
         # main stream's kernels keep CUs, there are half as many slabs to fold, and the launch still ends before the
         # next one is due (same-box sweep of the fill factor: 1.0 8.09-8.14, 0.7 7.86, 0.5 7.81-7.86, 0.35 7.86, 0.25
         # 9.26 ms/step). Alone on the GPU (single-stream runs, the per-kernel event pass of bench.py) it fills the chip.
-        fill = _side_fill(ctx, WGRAD_FILL) if (ctx.side is not None and PROFILER is None) else WGRAD_FILL_ALONE
+        fill = _side_fill(ctx, WGRAD_FILL) if (ctx.side is not None and not (PROFILER is not None and PROFILER.alone)) else WGRAD_FILL_ALONE
         nsplit = _wgrad_nsplit(tiles, B * H * W // WG_BKP, 9 * cout * cin, tm, tn, ctx.esize, taps_per_wg=3, fill=fill)
         part = ctx.wgrad_part(nsplit * 9 * cout * cin)
         if PROFILER is not None:
@@ -762,7 +767,7 @@ class UpPlan:
         mpad = tabx.numel()
         tm, tn = _wgrad_tiles(self.cin, self.cout, ctx.code)
         tiles = 4 * (self.cin // tm) * (self.cout // tn)
-        fill = _side_fill(ctx, WGRAD_FILL_T) if (ctx.side is not None and PROFILER is None) else 1.0
+        fill = _side_fill(ctx, WGRAD_FILL_T) if (ctx.side is not None and not (PROFILER is not None and PROFILER.alone)) else 1.0
         nsplit = _wgrad_nsplit(tiles, mpad // WG_BKP, 4 * self.cout * self.cin, tm, tn, ctx.esize, fill=fill)
         def weight_grad():
             with ctx.side_stream():
@@ -834,7 +839,7 @@ class OutConvPlan:
                 sink.view(self.mod.bias).copy_(self.folded[kc:])
 
         if dx is None:
-            if self.ctx.side is not None and PROFILER is None and dlogits.is_cuda:
+            if self.ctx.side is not None and not (PROFILER is not None and PROFILER.alone) and dlogits.is_cuda:
                 dlogits.record_stream(self.ctx.side)      # read on the side stream after the caller has dropped it
             with self.ctx.side_stream():
                 if self.fused_src is not None:       # the input activation was never stored: recompute it from y
