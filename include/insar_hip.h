@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define INSAR_ABI_VERSION 1
+#define INSAR_ABI_VERSION 2
 
 enum { INSAR_F32 = 0, INSAR_BF16 = 1 };
 
@@ -96,7 +96,15 @@ typedef struct InsarIgemm {
   int32_t ntaps;       /* 1, 4 or 9 */
   int32_t mode;        /* 0 | 1 */
   int8_t dy[12], dx[12];
+  int32_t flags;       /* INSAR_IGEMM_* */
+  int32_t out_stride;  /* mode 0: 0 / 1 = dense output; s > 1: GEMM row (ho, wo) is stored at output pixel (ho*s + out_oy, */
+  int32_t out_oy, out_ox; /*   wo*s + out_ox) — one parity class of the input gradient of a stride-s convolution */
+  int32_t _pad;
+  const void* add;     /* nullable, mode 0: a tensor with y's buffer layout (same C, c_off, dtype), added to the result */
 } InsarIgemm;
+/* flags. OOB_ZERO: taps may leave the padded input and read zeros there (dilated 3x3 convolutions of DeepLabV3's
+ * layer3 / layer4 / ASPP, torchvision resnet.py / deeplabv3.py; the 1-pixel halo covers only |dy|,|dx| <= 1). */
+enum { INSAR_IGEMM_OOB_ZERO = 1 };
 /* rows of the stats slab = number of M tiles the library will use for a GEMM with M rows and N columns
  * (the tile height, 128 or 256 pixels, is chosen from M and N so that the grid fills the 256 CUs). */
 int insar_igemm_num_mtiles(int64_t M, int32_t N);
@@ -144,6 +152,8 @@ typedef struct InsarWgrad {
   int32_t ntaps;
   int32_t offx[12];       /* per-tap pixel offset added to tabx entries */
   int32_t offdy[12];      /* per-tap pixel offset added to tabdy entries */
+  int64_t tabx_tap_stride; /* 0: tabx serves every tap (offx moves it); else tap t reads tabx + t*tabx_tap_stride (per-tap
+                            * tables from insar_pixel_table_taps: strided / dilated convolutions, out-of-bounds -> pixel 0) */
 } InsarWgrad;
 /* tile extent the kernel uses along a channel dimension of C channels: 64 | 128 | 256 (256 only when both
  * Cin and Cout allow it, otherwise capped at 128); needed by callers that size the split-K factor. */
@@ -385,6 +395,35 @@ int insar_confusion(const float* logits, const int64_t* target, int32_t B, int32
 int insar_adam_step(const int64_t* table, const int32_t* chunks, int32_t nchunks, int32_t chunk_elems,
                     float lr, float beta1, float beta2, float eps, float bias_correction1,
                     float bias_correction2_sqrt, float grad_scale, void* stream);
+
+/* ---- config 5: DeepLabV3-CA (DeepLabV3-ChannelAttention.py:83-162; backbone / ASPP arithmetic = torchvision's
+ * resnet50(replace_stride_with_dilation=[False,True,True]) + DeepLabHead, restated: csrc/deeplab.hip) -----------------
+ * Convolutions other than the stem run on insar_igemm (1x1 / 3x3, stride 1|2, dilation through the tap offsets with
+ * INSAR_IGEMM_OOB_ZERO) and insar_wgrad with per-tap tables: */
+int insar_pixel_table_taps(int32_t* tab /*[ntaps][Mpad]*/, int64_t Mpad, int32_t B, int32_t H, int32_t W, int32_t s,
+                           int32_t Hb, int32_t Wb, int32_t ntaps, const int8_t* dy, const int8_t* dx, void* stream);
+/* stem: Conv2d(1, 64, 7, stride 2, padding 3, bias=False) on the module input x (NCHW fp32 [B][1][H][W], :105-118).
+ * stats: [insar_conv7x7s2_fwd_rows(B, H)][2][64] BatchNorm partial sums (nullable).
+ * wgrad: part[insar_conv7x7s2_wgrad_blocks(B, H/2)][64*49] partial rows in torch (64,1,7,7) order. */
+int insar_conv7x7s2_fwd_rows(int32_t B, int32_t H);
+int insar_conv7x7s2_fwd(const float* x, int32_t H, int32_t W, const float* w, const InsarAct* y, float* stats, void* stream);
+int insar_conv7x7s2_wgrad_blocks(int32_t B, int32_t Ho);
+int insar_conv7x7s2_wgrad(const float* x, int32_t H, int32_t W, const InsarAct* dy, float* part, void* stream);
+/* MaxPool2d(3, stride 2, padding 1) of the stem: arg[B][Ho][Wo][C] = window position ky*3+kx of the first maximum. */
+int insar_maxpool3s2_fwd(const InsarAct* x, const InsarAct* y, uint8_t* arg, void* stream);
+int insar_maxpool3s2_bwd(const InsarAct* dy, const uint8_t* arg, const InsarAct* dx, void* stream);
+/* Bottleneck tail: dst = relu(y*scale + shift + res); and g = dout * (out > 0) (g may alias dout). */
+int insar_bn_add_relu(const InsarAct* y, const float* scale, const float* shift, const InsarAct* res, const InsarAct* dst,
+                      int32_t relu, void* stream);
+int insar_relu_gate_bwd(const InsarAct* dout, const InsarAct* out, const InsarAct* g, void* stream);
+/* ASPP pooling branch: out (B,1,1,C) = factor * sum_hw x;  dst (B,H,W,C) (+)= factor * src (B,1,1,C). */
+int insar_sum_hw(const InsarAct* x, const InsarAct* out, float factor, void* stream);
+int insar_broadcast_hw(const InsarAct* src, const InsarAct* dst, float factor, int32_t accumulate, void* stream);
+/* Dropout(p): make_mask != 0 draws mask[B][H][W][c_len] from (seed, element index) and stores it; == 0 applies `mask`. */
+int insar_dropout(const InsarAct* x, const InsarAct* dst, uint8_t* mask, uint64_t seed, float p, int32_t make_mask, void* stream);
+/* F_T.resize(x, size, BILINEAR) (:160): bilinear, align_corners = False, on `planes` fp32 maps; and its adjoint. */
+int insar_bilinear_fwd(const float* in, float* out, int32_t planes, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, void* stream);
+int insar_bilinear_bwd(const float* dout, float* din, int32_t planes, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, void* stream);
 
 /* ---- small helpers ---------------------------------------------------------------------------- */
 int insar_scale_f32(float* p, int64_t n, float s, void* stream);

@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INSAR_HIP_LIB") or os.path.join(_HERE, "libinsar_hip.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
+IGEMM_OOB_ZERO = 1
 
 
 class InsarAct(C.Structure):
@@ -28,13 +29,14 @@ class InsarIgemm(C.Structure):
     _fields_ = [("x", InsarAct), ("y", InsarAct), ("w", C.c_void_p), ("bias", C.c_void_p),
                 ("stats", C.c_void_p), ("N", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
                 ("stride", C.c_int32), ("ntaps", C.c_int32), ("mode", C.c_int32),
-                ("dy", C.c_int8 * 12), ("dx", C.c_int8 * 12)]
+                ("dy", C.c_int8 * 12), ("dx", C.c_int8 * 12), ("flags", C.c_int32), ("out_stride", C.c_int32),
+                ("out_oy", C.c_int32), ("out_ox", C.c_int32), ("_pad", C.c_int32), ("add", C.c_void_p)]
 
 
 class InsarWgrad(C.Structure):
     _fields_ = [("x", InsarAct), ("dy", InsarAct), ("tabx", C.c_void_p), ("tabdy", C.c_void_p),
                 ("part", C.c_void_p), ("Mpad", C.c_int64), ("nsplit", C.c_int32), ("ntaps", C.c_int32),
-                ("offx", C.c_int32 * 12), ("offdy", C.c_int32 * 12)]
+                ("offx", C.c_int32 * 12), ("offdy", C.c_int32 * 12), ("tabx_tap_stride", C.c_int64)]
 
 
 class InsarBnFinalize(C.Structure):
@@ -144,6 +146,20 @@ _SIGNATURES = {
     "insar_confusion": [_P, _P, _I, _I, _L, _L, _P, _P],
     "insar_adam_step": [_P, _P, _I, _I, _F, _F, _F, _F, _F, _F, _F, _P],
     "insar_scale_f32": [_P, _L, _F, _P],
+    "insar_pixel_table_taps": [_P, _L, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "insar_conv7x7s2_fwd_rows": [_I, _I],
+    "insar_conv7x7s2_fwd": [_P, _I, _I, _P, _AP, _P, _P],
+    "insar_conv7x7s2_wgrad_blocks": [_I, _I],
+    "insar_conv7x7s2_wgrad": [_P, _I, _I, _AP, _P, _P],
+    "insar_maxpool3s2_fwd": [_AP, _AP, _P, _P],
+    "insar_maxpool3s2_bwd": [_AP, _P, _AP, _P],
+    "insar_bn_add_relu": [_AP, _P, _P, _AP, _AP, _I, _P],
+    "insar_relu_gate_bwd": [_AP, _AP, _AP, _P],
+    "insar_sum_hw": [_AP, _AP, _F, _P],
+    "insar_broadcast_hw": [_AP, _AP, _F, _I, _P],
+    "insar_dropout": [_AP, _AP, _P, C.c_uint64, _F, _I, _P],
+    "insar_bilinear_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "insar_bilinear_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["insar_version", "insar_last_error"])
 
@@ -179,7 +195,7 @@ def load():
 
 
 _COUNT_ONLY = {"insar_igemm_num_mtiles", "insar_igemm_tile_rows", "insar_igemm_tile_cols", "insar_igemm_tile_cols_dt", "insar_wgrad_tile", "insar_wgrad_tile_pair", "insar_wgrad_conv3_tile", "insar_conv3x3_flat_ok", "insar_conv3x3_flat_num_mtiles", "insar_conv3x3_c64_ok", "insar_conv3x3_c64_rows", "insar_conv3x3_c64_geometry", "insar_conv3x3_small_wgrad_blocks", "insar_conv3x3_small_fwd_rows", "insar_conv1x1_out_bwd_blocks",
-               "insar_ce_blocks"}
+               "insar_ce_blocks", "insar_conv7x7s2_fwd_rows", "insar_conv7x7s2_wgrad_blocks"}
 
 
 def call(name: str, *args) -> int:

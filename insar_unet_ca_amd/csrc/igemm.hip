@@ -36,6 +36,9 @@ struct IgemmArgs {
   int kc_per_tap;
   int num_mtiles, num_ntiles;
   int tapoff[12];  // element offset of each tap relative to the tap-(0,0) pixel
+  signed char tdy[12], tdx[12];   // the taps themselves (OOB variant: per-row bounds test)
+  int out_stride, out_oy, out_ox;   // mode 0: row (ho, wo) is stored at output pixel (ho*out_stride + out_oy, wo*out_stride + out_ox)
+  const char* add; // nullable: tensor with y's layout added to the result in the epilogue (residual / gradient sum)
 };
 
 __device__ __forceinline__ void lds_dma16(const char* gsrc, char* lds_wave_base) {
@@ -73,9 +76,9 @@ struct IgemmCfg {
   static constexpr int PITCH = BN * ES + 16;               // epilogue tile row pitch (bytes)
   static constexpr int TILE = BM * PITCH;
   static constexpr int MAIN = (NSTAGE * STAGE > TILE) ? NSTAGE * STAGE : TILE;
-  static constexpr int ROWINFO = BM * 8 * 2;               // rowIn[BM], rowOut[BM] (int64)
+  static constexpr int ROWINFO = BM * 8 * 2 + BM * 4;      // rowIn[BM], rowOut[BM] (int64), rowHW[BM] (int32)
   static constexpr int STATB = NWAVES * BN * 2 * 4;        // per-wave channel partials
-  static constexpr int TAPB = 64;                           // tap offsets (12 ints)
+  static constexpr int TAPB = 64 + 32;                      // tap offsets (12 ints), tap dy/dx (12 + 12 bytes)
   static constexpr int LDS_BYTES = MAIN + ROWINFO + STATB + TAPB;
 };
 
@@ -86,7 +89,10 @@ __device__ __forceinline__ void dma_wait_and_barrier() {
   __builtin_amdgcn_s_barrier();
 }
 
-template <typename T, int BM, int BN, int NSTAGE>
+// OOB: taps may leave the padded input (dilated convolutions, DeepLabV3's ASPP / layer3-4): such (row, tap) pairs
+// are redirected to pixel 0 of the buffer — the top-left halo pixel, all zeros in every channel — by a per-row bounds
+// test on the LDS-DMA source address; rows beyond M read zeros the same way. The U-Net path never needs it.
+template <typename T, int BM, int BN, int NSTAGE, bool OOB = false>
 __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(IgemmArgs a) {
   using Cfg = IgemmCfg<T, BM, BN, NSTAGE>;
   constexpr int ES = Cfg::ES, BKe = Cfg::BKe, CH = Chunk<T>::N;
@@ -95,6 +101,7 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
   extern __shared__ __attribute__((aligned(16))) char smem[];
   long long* rowIn = (long long*)(smem + Cfg::MAIN);
   long long* rowOut = rowIn + BM;
+  int* rowHW = (int*)(rowOut + BM);
   float* sstat = (float*)(smem + Cfg::MAIN + Cfg::ROWINFO);
   int* stap = (int*)(smem + Cfg::MAIN + Cfg::ROWINFO + Cfg::STATB);
 
@@ -114,6 +121,9 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
   if (tid == THREADS - 1) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) stap[i] = a.tapoff[i];
+    signed char* sd = (signed char*)(stap + 16);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { sd[i] = a.tdy[i]; sd[16 + i] = a.tdx[i]; }
   }
   if (tid < BM) {
     const long long m = m0 + tid;
@@ -124,9 +134,11 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
     const int rem = (int)(mm - (long long)n * hw);
     const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
     rowIn[tid] = (((long long)n * (a.Hi + 2) + ho * a.stride + 1) * (a.Wi + 2) + wo * a.stride + 1) * a.Cx + a.cx_off;
-    const int so = a.mode == 1 ? 2 : 1;
-    const long long ro = (((long long)n * (a.Hy + 2) + ho * so + 1) * (a.Wy + 2) + wo * so + 1) * a.Cy + a.cy_off;
+    const int so = a.mode == 1 ? 2 : a.out_stride;
+    const long long ro = (((long long)n * (a.Hy + 2) + ho * so + a.out_oy + 1) * (a.Wy + 2) + wo * so + a.out_ox + 1) * a.Cy + a.cy_off;
     rowOut[tid] = valid ? ro : -1;
+    // input coordinates of tap (0,0), biased by +1 (halo) and packed; rows beyond M get a row no tap can reach
+    rowHW[tid] = valid ? (((ho * a.stride + 1) << 16) | (wo * a.stride + 1)) : (0x4000 << 16);
   }
   __syncthreads();
 
@@ -135,8 +147,13 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
   const int srow = tid >> 3;                        // + RPI*i
   const int schunk = ((tid & 7) ^ (srow & 7)) * 16; // swizzled source chunk (bytes)
   const char* a_ptr[Cfg::A_DMA];
+  int a_hw[Cfg::A_DMA];
 #pragma unroll
-  for (int i = 0; i < Cfg::A_DMA; ++i) a_ptr[i] = a.x + rowIn[srow + RPI * i] * ES + schunk;
+  for (int i = 0; i < Cfg::A_DMA; ++i) {
+    a_ptr[i] = a.x + rowIn[srow + RPI * i] * ES + schunk;
+    a_hw[i] = OOB ? rowHW[srow + RPI * i] : 0;
+  }
+  const char* a_zero = a.x + (long long)a.cx_off * ES + schunk;      // pixel 0 = zero halo
   const long long b_row_bytes = (long long)a.K * ES;
   const char* b_ptr = a.w + ((long long)(n0 + srow) * a.K) * ES + schunk;
   const long long b_tap_bytes = (long long)a.N * a.K * ES;
@@ -148,8 +165,20 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
     const int kc = ks - tap * a.kc_per_tap;
     const long long xoff = ((long long)stap[tap] + (long long)kc * BKe) * ES;
     const uint32_t la = lds0 + buf * Cfg::STAGE + wave * 1024;
+    if constexpr (OOB) {
+      const signed char* sd = (const signed char*)(stap + 16);
+      const int tdy = sd[tap], tdx = sd[16 + tap];
+      const long long koff = (long long)kc * BKe * ES;
 #pragma unroll
-    for (int i = 0; i < Cfg::A_DMA; ++i) lds_dma16_untracked(a_ptr[i] + xoff, la + i * (THREADS * 16));
+      for (int i = 0; i < Cfg::A_DMA; ++i) {
+        const int hh = (a_hw[i] >> 16) + tdy, ww = (a_hw[i] & 0xffff) + tdx;      // padded coordinates of the tap
+        const bool in = (unsigned)hh <= (unsigned)(a.Hi + 1) && (unsigned)ww <= (unsigned)(a.Wi + 1);
+        lds_dma16_untracked(in ? a_ptr[i] + xoff : a_zero + koff, la + i * (THREADS * 16));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < Cfg::A_DMA; ++i) lds_dma16_untracked(a_ptr[i] + xoff, la + i * (THREADS * 16));
+    }
     const char* wb = b_ptr + tap * b_tap_bytes + (long long)kc * BKe * ES;
     const uint32_t lb = la + Cfg::A_STAGE;
 #pragma unroll
@@ -251,6 +280,12 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
       Chunk<T>::unpack(*(const uint4*)(tile + row * Cfg::PITCH + cc * 16), f);
 #pragma unroll
       for (int j = 0; j < CH; ++j) { s1[j] += f[j]; s2[j] = fmaf(f[j], f[j], s2[j]); f[j] += bias[j]; }
+      if (a.add) {
+        float g[CH];
+        Chunk<T>::unpack(*(const uint4*)(a.add + (ro + col_off) * ES), g);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) f[j] += g[j];
+      }
       *(uint4*)(a.y + (ro + col_off) * ES) = Chunk<T>::pack(f);
     }
   }
@@ -322,18 +357,18 @@ extern "C" int insar_igemm_num_mtiles(int64_t M, int32_t N) {
   return (int)((M + bm - 1) / bm);
 }
 
-template <typename T, int BM, int BN, int NSTAGE>
+template <typename T, int BM, int BN, int NSTAGE, bool OOB = false>
 static int launch_igemm(IgemmArgs& a, hipStream_t s) {
   using Cfg = IgemmCfg<T, BM, BN, NSTAGE>;
   static std::atomic<uint64_t> attr_mask{0};     // per-device, see common.h
   {
-    hipError_t e = insar_set_lds_once(attr_mask, (const void*)igemm_kernel<T, BM, BN, NSTAGE>, Cfg::LDS_BYTES);
+    hipError_t e = insar_set_lds_once(attr_mask, (const void*)igemm_kernel<T, BM, BN, NSTAGE, OOB>, Cfg::LDS_BYTES);
     if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_igemm: hipFuncSetAttribute(%d bytes LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
   }
   a.num_mtiles = (int)((a.M + BM - 1) / BM);
   a.num_ntiles = a.N / BN;
   const int grid = a.num_mtiles * a.num_ntiles;
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, NSTAGE>), dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, NSTAGE, OOB>), dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, a);
   INSAR_CHECK_LAUNCH("insar_igemm");
   return INSAR_OK;
 }
@@ -354,14 +389,23 @@ extern "C" int insar_igemm(const InsarIgemm* d, void* stream) {
   if (d->x.B != d->y.B) INSAR_FAIL(INSAR_E_SHAPE, "insar_igemm: batch differs");
   if (!insar_aligned16(d->w)) INSAR_FAIL(INSAR_E_ALIGN, "insar_igemm: weights not 16-byte aligned");
   int cout = d->N;
+  const int os = d->out_stride > 0 ? d->out_stride : 1;
   if (d->mode == 0) {
-    if (d->y.H != d->Ho || d->y.W != d->Wo || d->y.c_len != d->N) INSAR_FAIL(INSAR_E_SHAPE, "insar_igemm: output slice does not match Ho/Wo/N");
+    if (os == 1 && (d->out_oy || d->out_ox)) INSAR_FAIL(INSAR_E_ARG, "insar_igemm: output offset without an output stride");
+    if (d->out_oy < 0 || d->out_ox < 0 || d->out_oy >= os || d->out_ox >= os) INSAR_FAIL(INSAR_E_ARG, "insar_igemm: output offset outside [0, out_stride)");
+    const bool fits = os == 1 ? (d->y.H == d->Ho && d->y.W == d->Wo)
+                              : ((d->Ho - 1) * os + d->out_oy < d->y.H && (d->Wo - 1) * os + d->out_ox < d->y.W);
+    if (!fits || d->y.c_len != d->N) INSAR_FAIL(INSAR_E_SHAPE, "insar_igemm: output slice does not match Ho/Wo/N");
   } else if (d->mode == 1) {
     cout = d->N / 4;
     if (d->y.H != 2 * d->Ho || d->y.W != 2 * d->Wo || d->y.c_len != cout || (cout % 8)) INSAR_FAIL(INSAR_E_SHAPE, "insar_igemm: convT output slice mismatch");
   } else INSAR_FAIL(INSAR_E_ARG, "insar_igemm: mode=%d", d->mode);
-  // every tap of every row must stay inside the padded input
-  for (int t = 0; t < d->ntaps; ++t) {
+  const bool oob = (d->flags & INSAR_IGEMM_OOB_ZERO) != 0;
+  if (oob && d->x.H + 2 > 0x3fff) INSAR_FAIL(INSAR_E_SHAPE, "insar_igemm: input too tall for the out-of-bounds variant");
+  if (d->add && d->mode != 0) INSAR_FAIL(INSAR_E_ARG, "insar_igemm: `add` needs mode 0");
+  if (d->add && !insar_aligned16(d->add)) INSAR_FAIL(INSAR_E_ALIGN, "insar_igemm: add not 16-byte aligned");
+  // every tap of every row must stay inside the padded input (unless out-of-bounds taps read zeros)
+  for (int t = 0; t < d->ntaps && !oob; ++t) {
     const int ymin = d->dy[t], ymax = (d->Ho - 1) * d->stride + d->dy[t];
     const int xmin = d->dx[t], xmax = (d->Wo - 1) * d->stride + d->dx[t];
     if (ymin < -1 || xmin < -1 || ymax > d->x.H || xmax > d->x.W)
@@ -375,10 +419,19 @@ extern "C" int insar_igemm(const InsarIgemm* d, void* stream) {
   a.Hy = d->y.H; a.Wy = d->y.W; a.Cy = d->y.C; a.cy_off = d->y.c_off;
   a.N = d->N; a.ntaps = d->ntaps; a.mode = d->mode; a.Cout = cout;
   a.kc_per_tap = K / bke;
-  for (int t = 0; t < 12; ++t) a.tapoff[t] = t < d->ntaps ? (d->dy[t] * (d->x.W + 2) + d->dx[t]) * d->x.C : 0;
+  for (int t = 0; t < 12; ++t) {
+    a.tapoff[t] = t < d->ntaps ? (d->dy[t] * (d->x.W + 2) + d->dx[t]) * d->x.C : 0;
+    a.tdy[t] = t < d->ntaps ? d->dy[t] : 0; a.tdx[t] = t < d->ntaps ? d->dx[t] : 0;
+  }
+  a.add = (const char*)d->add;
+  a.out_stride = os; a.out_oy = d->mode == 0 ? d->out_oy : 0; a.out_ox = d->mode == 0 ? d->out_ox : 0;
   hipStream_t s = (hipStream_t)stream;
   const bool wide = igemm_bn_for(a.M, d->N) == 128;
   const bool big = igemm_bm_for(a.M, d->N) == 256;
+  if (oob) {     // dilated taps: two tile shapes per dtype are enough for the DeepLabV3 layers (32x32 maps at B = 16)
+    if (d->x.dtype == INSAR_BF16) return big ? launch_igemm<bf16_t, 256, 64, 3, true>(a, s) : launch_igemm<bf16_t, 128, 64, 2, true>(a, s);
+    return big ? launch_igemm<float, 256, 64, 3, true>(a, s) : launch_igemm<float, 128, 64, 2, true>(a, s);
+  }
   if (d->x.dtype == INSAR_BF16) {
     if (igemm_xwide(a.M, d->N, INSAR_BF16)) return launch_igemm<bf16_t, 256, 256, 2>(a, s);
     if (big) return wide ? launch_igemm<bf16_t, 256, 128, 3>(a, s) : launch_igemm<bf16_t, 256, 64, 3>(a, s);

@@ -33,6 +33,7 @@ struct WgradArgs {
   int Cx, cx_off, Cin; int Cdy, cdy_off, Cout;
   int mtc, ntc;
   int offx[12], offdy[12];
+  long long tabx_tap_stride;   // 0: one x table for every tap; else table of tap t starts at tabx + t*stride
 };
 
 
@@ -117,9 +118,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad_kernel(Wgrad
   const long long xpitch = (long long)a.Cx * ES, ypitch = (long long)a.Cdy * ES;
 
   int32_t px[Cfg::NX], py[Cfg::NY];
+  const int32_t* tabx_tap = a.tabx + (long long)tap * a.tabx_tap_stride;
   auto load_tabs = [&](long long ks) {
 #pragma unroll
-    for (int i = 0; i < Cfg::NX; ++i) px[i] = a.tabx[ks * WG_BKP + xrow_i[i]];
+    for (int i = 0; i < Cfg::NX; ++i) px[i] = tabx_tap[ks * WG_BKP + xrow_i[i]];
 #pragma unroll
     for (int i = 0; i < Cfg::NY; ++i) py[i] = a.tabdy[ks * WG_BKP + yrow_i[i]];
   };
@@ -293,6 +295,7 @@ extern "C" int insar_wgrad(const InsarWgrad* d, void* stream) {
   a.Cx = d->x.C; a.cx_off = d->x.c_off; a.Cin = Cin;
   a.Cdy = d->dy.C; a.cdy_off = d->dy.c_off; a.Cout = Cout;
   for (int t = 0; t < 12; ++t) { a.offx[t] = t < d->ntaps ? d->offx[t] : 0; a.offdy[t] = t < d->ntaps ? d->offdy[t] : 0; }
+  a.tabx_tap_stride = d->tabx_tap_stride;
   hipStream_t s = (hipStream_t)stream;
   int tm, tn;
   wgrad_tile_pair(Cin, Cout, d->x.dtype, tm, tn);

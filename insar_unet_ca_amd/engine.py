@@ -138,6 +138,24 @@ class Ctx:
         return self._tables[key]
 
 
+def _taps_table(self, B: int, Ho: int, Wo: int, s: int, Hb: int, Wb: int, taps) -> torch.Tensor:
+    """Per-tap pixel tables [ntaps][Mpad] for insar_wgrad (strided / dilated convolutions): entry = padded pixel index of
+    (n, ho*s + dy, wo*s + dx) in a (Hb, Wb) buffer, or 0 (the zero halo corner) outside it."""
+    key = ("taps", B, Ho, Wo, s, Hb, Wb, tuple(taps))
+    if key not in self._tables:
+        mpad = _round_up(B * Ho * Wo, WG_BKP)
+        t = torch.empty(len(taps) * mpad, dtype=torch.int32, device=self.device)
+        dy = (C.c_int8 * 12)(*([a for a, _ in taps] + [0] * (12 - len(taps))))
+        dx = (C.c_int8 * 12)(*([b for _, b in taps] + [0] * (12 - len(taps))))
+        call("insar_pixel_table_taps", ptr(t), mpad, B, Ho, Wo, s, Hb, Wb, len(taps), C.addressof(dy), C.addressof(dx),
+             _lib.stream_ptr())
+        self._tables[key] = t
+    return self._tables[key]
+
+
+Ctx.taps_table = _taps_table
+
+
 class GemmWeight:
     """GEMM-operand copies ([tap][n][k], compute dtype) of a Conv2d / ConvTranspose2d weight: the forward
     form and the transposed / flipped input-gradient form. Refreshed when the fp32 master parameter changes
@@ -145,9 +163,10 @@ class GemmWeight:
 
     def __init__(self, ctx: Ctx, param: torch.nn.Parameter, kind: str):
         self.ctx, self.param, self.kind = ctx, param, kind
-        if kind == "conv3":
+        if kind == "conv3":           # any Conv2d (Co, Ci, k, k): T = k*k taps in raster order
             co, ci = param.shape[0], param.shape[1]
-            self._spec = {"fwd": (9, co, ci, 1, ci * 9, 9), "dgrad": (9, ci, co, 1, 9, ci * 9)}
+            T = param.shape[2] * param.shape[3]
+            self._spec = {"fwd": (T, co, ci, 1, ci * T, T), "dgrad": (T, ci, co, 1, T, ci * T)}
         else:       # convT (Ci, Co, 2, 2): forward rows n = q*Co + co
             ci, co = param.shape[0], param.shape[1]
             self._spec = {"fwd": (4, co, ci, 1, 4, co * 4), "dgrad": (4, ci, co, 1, co * 4, 4)}
@@ -260,22 +279,32 @@ _TAPS3_DGRAD = [(1 - r, 1 - s) for r in range(3) for s in range(3)]
 _TAPS2 = [(a, b) for a in range(2) for b in range(2)]
 
 
-def _igemm(x: Act, y: Act, w: torch.Tensor, N: int, Ho: int, Wo: int, stride: int, taps, mode: int,
-           bias: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None) -> None:
+def _igemm(x: Act, y: Act, w, N: int, Ho: int, Wo: int, stride: int, taps, mode: int,
+           bias: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, oob: bool = False,
+           add: Optional[Act] = None, out_stride: int = 1, out_off=(0, 0)) -> None:
+    """w: tensor, or a raw device pointer (a tap slice of a GEMM-layout weight)."""
     d = InsarIgemm()
     d.x, d.y = x.desc, y.desc
-    d.w, d.bias, d.stats = ptr(w), ptr(bias), ptr(stats)
+    d.w, d.bias, d.stats = (w if isinstance(w, int) else ptr(w)), ptr(bias), ptr(stats)
     d.N, d.Ho, d.Wo, d.stride, d.ntaps, d.mode = N, Ho, Wo, stride, len(taps), mode
+    d.flags = _lib.IGEMM_OOB_ZERO if oob else 0
+    d.out_stride, d.out_oy, d.out_ox = out_stride, out_off[0], out_off[1]
+    if add is not None:
+        if add.C != y.C or add.c_off != y.c_off or add.buf.dtype != y.buf.dtype or add.buf.shape != y.buf.shape:
+            raise _lib.InsarError("igemm: `add` must have the output's buffer layout")
+        d.add = add.buf.data_ptr()
     for i, (dy, dx) in enumerate(taps):
         d.dy[i], d.dx[i] = dy, dx
     if PROFILER is not None:
         flops = 2.0 * x.B * Ho * Wo * N * x.c_len * len(taps)
         bm = call("insar_igemm_tile_rows", x.B * Ho * Wo, N)
         bn = call("insar_igemm_tile_cols_dt", x.B * Ho * Wo, N, x.code)
-        tag = "igemm_kernel<%s, %d, %d, %d>" % ("float" if x.code == _lib.F32 else "bf16_t", bm, bn,
-                                                3 if bm == 256 and bn < 256 else 2)
+        if oob:
+            bn = 64
+        tag = "igemm_kernel<%s, %d, %d, %d%s>" % ("float" if x.code == _lib.F32 else "bf16_t", bm, bn,
+                                                  3 if bm == 256 and bn < 256 else 2, ", oob" if oob else "")
         es = 2 if x.code == _lib.BF16 else 4      # operands each read once, output written once
-        nbytes = es * (x.B * x.H * x.W * x.c_len + y.B * y.H * y.W * y.c_len + w.numel())
+        nbytes = es * (x.B * x.H * x.W * x.c_len + y.B * y.H * y.W * y.c_len + len(taps) * N * x.c_len)
         PROFILER.run(tag, flops, lambda: call("insar_igemm", C.byref(d), _lib.stream_ptr()), nbytes)
         return
     call("insar_igemm", C.byref(d), _lib.stream_ptr())

@@ -1,0 +1,226 @@
+"""GPU parity of config 5, DeepLabV3-CA (DeepLabV3-ChannelAttention.py:83-162), against oracle/deeplab_oracle.py.
+PARITY UNPINNED for the torchvision part of the network (torchvision is absent, its loader fetches weights);
+ChannelAttentionModule itself is pinned by fixture G7 (tests/test_parity_gpu.py). What these tests establish is that
+the HIP plan computes the published DeepLabV3-ResNet50 architecture as the oracle restates it: forward <= 1e-3 (fp32),
+parameter gradients, BatchNorm buffers, dropout under a given mask, Adam steps, and the bf16 benchmark geometry."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import deeplab_oracle as dlo
+from tests.helpers import max_rel, to_np
+
+pytestmark = pytest.mark.gpu
+FWD_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm device")
+    from insar_unet_ca_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def rel_l2(a, b):
+    a, b = to_np(a), to_np(b)
+    den = np.linalg.norm(b)
+    return float(np.linalg.norm(a - b) / (den if den > 0 else 1.0))
+
+
+def _make(dev, seed, dtype=torch.float32, p_drop=None):
+    import insar_unet_ca_amd as iu
+    torch.manual_seed(seed)
+    net = iu.DeepLabV3_SingleChannel_Attn(num_classes=2, backbone="resnet50", pretrained=False, compute_dtype=dtype)
+    # generic-position BatchNorm parameters and buffers (the default gamma = 1, beta = 0, mean 0, var 1 hide mistakes)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(1.0 + 0.2 * torch.randn(m.weight.shape, generator=g))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+                m.running_mean.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+                m.running_var.copy_(1.0 + 0.2 * torch.rand(m.bias.shape, generator=g))
+    if p_drop is not None:
+        net.aspp.project[3].p = p_drop
+    sd = OrderedDict((k, v.detach().clone()) for k, v in net.state_dict().items())
+    # re-alias the clone like the reference's state_dict (model.backbone.* is backbone.*, ...)
+    tmpl = dlo.state_dict_template(2)
+    owner = {}
+    for k, v in tmpl.items():
+        owner.setdefault(v.data_ptr() if v.numel() else id(v), k)
+    for k, v in tmpl.items():
+        first = owner[v.data_ptr() if v.numel() else id(v)]
+        if first != k:
+            sd[k] = sd[first]
+    return net.to(dev), sd
+
+
+def _input(shape, seed):
+    from insar_unet_ca_amd.data import make_batch
+    x, y = make_batch(seed, shape[0], shape[2], channels=1)
+    return x, y
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 64, 64), (2, 1, 128, 128), (3, 1, 96, 160)])
+def test_deeplab_eval_forward_against_oracle(dev, shape):
+    net, sd = _make(dev, 11)
+    net.eval()
+    x, _ = _input(shape, 5) if shape[2] == shape[3] else (torch.randn(shape, generator=torch.Generator().manual_seed(3)).clamp(-1, 1), None)
+    with torch.no_grad():
+        got = net(x.to(dev))
+        ref = dlo.forward(sd, x, training=False)
+    assert got.shape == ref.shape == (shape[0], 2, shape[2], shape[3])
+    err = max_rel(got, ref)
+    print(f"DeepLabV3-CA eval {shape}: logits max-rel {err:.3e}")
+    assert err <= FWD_TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 64, 64), (2, 1, 128, 128)])
+def test_deeplab_train_forward_backward_against_oracle(dev, shape):
+    import insar_unet_ca_amd as iu
+    net, sd = _make(dev, 21, p_drop=0.0)
+    net.train()
+    x, y = _input(shape, 9)
+    names = [k for k in dlo.primary_keys(sd) if dlo.is_param(k)]
+    work = OrderedDict(sd)
+    leaves = {}
+    for k in names:
+        leaves[k] = sd[k].clone().requires_grad_(True)
+    for k in list(work.keys()):            # aliases follow their owner
+        for owner in names:
+            if work[k] is sd[owner]:
+                work[k] = leaves[owner]
+    ref = dlo.forward(work, x, training=True)
+    ref_loss = dlo.cross_entropy(ref, y)
+    grads = dict(zip(names, torch.autograd.grad(ref_loss, [leaves[k] for k in names])))
+    logits = net(x.to(dev))
+    loss = iu.CrossEntropyLoss(ignore_index=255)(logits, y.to(dev))
+    loss.backward()
+    err = max_rel(logits, ref)
+    print(f"DeepLabV3-CA train {shape}: logits max-rel {err:.3e}, loss {float(loss):.6f} vs {float(ref_loss):.6f}")
+    assert err <= FWD_TOL
+    assert abs(float(loss) - float(ref_loss)) <= 1e-4 * max(1.0, abs(float(ref_loss)))
+    # BatchNorm buffers after the training-mode forward (the oracle updated `work` in place)
+    got_sd = net.state_dict()
+    for k in ("model.backbone.bn1.running_mean", "model.backbone.layer2.0.downsample.1.running_var",
+              "model.backbone.layer4.2.bn2.running_var", "model.classifier.0.convs.4.2.running_mean",
+              "model.classifier.0.convs.2.1.running_var", "model.classifier.2.running_mean"):
+        assert max_rel(got_sd[k], work[k]) <= 1e-3, k
+    assert int(got_sd["model.backbone.layer3.5.bn3.num_batches_tracked"]) == 1
+    # parameter gradients: every tensor by relative L2 (ReLU / max-pool decisions that sit within rounding of a tie move
+    # a few elements), the layers next to the loss tightly
+    got = {k: p.grad for k, p in net.named_parameters()}
+    worst = {}
+    for k in names:
+        r = rel_l2(got[k], grads[k])
+        worst[k] = r
+        scale = float(grads[k].abs().max())
+        if scale < 1e-12:
+            assert float(got[k].abs().max()) < 1e-9, k
+    bad = {k: v for k, v in worst.items() if v > 2e-2 and float(grads[k].abs().max()) >= 1e-12}
+    print("worst gradient rel-L2:", sorted(worst.items(), key=lambda kv: -kv[1])[:5])
+    assert not bad, bad
+    for k in ("model.classifier.4.weight", "model.classifier.4.bias", "attention_module.mlp.0.weight", "attention_module.mlp.2.weight",
+              "model.classifier.1.weight", "model.classifier.0.project.0.weight"):
+        assert worst[k] <= 2e-3, (k, worst[k])
+    assert np.median(list(worst.values())) <= 1e-3
+
+
+def test_deeplab_dropout_under_a_given_mask_and_adam_steps(dev):
+    """Training mode with Dropout(0.5): the HIP path draws its own mask (torch's Philox stream cannot be reproduced); the
+    oracle is given that mask. Then three Adam steps on both sides with externally supplied masks: the loss curves agree."""
+    import insar_unet_ca_amd as iu
+    net, sd = _make(dev, 31)
+    net.train()
+    shape = (4, 1, 64, 64)
+    x, y = _input(shape, 17)
+    logits = net(x.to(dev))
+    plan = next(iter(net._plans.plans.values()))[0]
+    mask = plan.drop_mask.permute(0, 3, 1, 2).contiguous().cpu()           # [B,256,h,w] of 0/1
+    keep = float(mask.float().mean())
+    assert 0.4 < keep < 0.6
+    ref = dlo.forward(OrderedDict(sd), x, training=True, dropout_mask=mask)
+    assert max_rel(logits, ref) <= FWD_TOL
+    # Adam steps under given masks (p.grad / optimizer path of the drop-in)
+    del logits
+    net2, sd2 = _make(dev, 32)
+    net2.train()
+    crit = iu.CrossEntropyLoss(ignore_index=255)
+    opt = iu.Adam(net2.parameters(), lr=1e-4)
+    names = [k for k in dlo.primary_keys(sd2) if dlo.is_param(k)]
+    ref_params = [sd2[k].clone().requires_grad_(True) for k in names]
+    ropt = torch.optim.Adam(ref_params, lr=1e-4)
+    gen = torch.Generator().manual_seed(5)
+    hip_losses, ref_losses = [], []
+    plan2 = None
+    for step in range(3):
+        m = (torch.rand((4, 256, 8, 8), generator=gen) >= 0.5).to(torch.uint8)
+        if plan2 is None:
+            with torch.no_grad():
+                net2(x.to(dev))                                              # builds the plan (and moves the BN buffers once)
+            plan2 = next(iter(net2._plans.plans.values()))[0]
+            plan2.external_mask = True
+            net2.load_state_dict({k: v for k, v in sd2.items()})            # undo that forward's buffer update
+        plan2.drop_mask.copy_(m.permute(0, 2, 3, 1).contiguous().to(dev))
+        opt.zero_grad()
+        l = crit(net2(x.to(dev)), y.to(dev))
+        l.backward()
+        opt.step()
+        hip_losses.append(float(l))
+        work = OrderedDict(sd2)
+        for k, p in zip(names, ref_params):
+            for kk in list(work.keys()):
+                if work[kk] is sd2[k]:
+                    work[kk] = p
+        ropt.zero_grad()
+        rl = dlo.cross_entropy(dlo.forward(work, x, training=True, dropout_mask=m), y)
+        rl.backward()
+        ropt.step()
+        ref_losses.append(float(rl))
+    print("DeepLabV3-CA 3 Adam steps: HIP", hip_losses, "oracle", ref_losses)
+    assert all(abs(a - b) <= 2e-3 * max(1.0, abs(b)) for a, b in zip(hip_losses, ref_losses))
+
+
+def test_deeplab_bf16_config5_geometry(dev):
+    """BASELINE.json config 5: DeepLabV3-CA bf16, batch 16 of 1 x 256 x 256: runs, is finite, tracks the fp32 HIP path
+    (bf16 storage, fp32 accumulation / statistics), is bitwise reproducible, and trains."""
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd.data import make_batch
+    x, y = make_batch(0, 16, 256, channels=1)
+    x, y = x.to(dev), y.to(dev)
+    net32, _ = _make(dev, 41, p_drop=0.0)
+    net32.train()
+    ref = net32(x).detach()
+    net32._plans.clear()
+    del net32
+    torch.cuda.empty_cache()
+    net, _ = _make(dev, 41, dtype=torch.bfloat16, p_drop=0.0)
+    net.train()
+    crit = iu.CrossEntropyLoss(ignore_index=255)
+    opt = iu.Adam(net.parameters(), lr=1e-4)
+    logits = net(x)
+    err = max_rel(logits, ref)
+    agree = (logits.argmax(1) == ref.argmax(1)).float().mean().item()
+    print(f"config 5 bf16 vs fp32 HIP: max-rel {err:.3e}, arg-max agreement {agree:.4f}")
+    assert err <= 0.15 and agree >= 0.97
+    opt.zero_grad()
+    l1 = crit(logits, y)
+    l1.backward()
+    g1 = [p.grad.clone() for p in net.parameters()]
+    opt.zero_grad()
+    l2 = crit(net(x), y)
+    l2.backward()
+    assert float(l1) == float(l2) and all(torch.equal(a, p.grad) for a, p in zip(g1, net.parameters()))
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+    first = float(l2)
+    for _ in range(6):
+        opt.zero_grad()
+        l = crit(net(x), y)
+        l.backward()
+        opt.step()
+    assert float(l) < first

@@ -243,3 +243,31 @@ def test_c64_ring_never_overwrites_a_live_row():
                 assert not (live & new), f"W={W}, tile {t}: {len(live & new)} prefetched rows alias live rows (R={R})"
         checked += 1
     assert checked > 100
+
+
+def test_deeplab_state_dict_contract_and_tap_logic():
+    """Config 5's module tree carries the names / shapes / order of the reference wrapper's state_dict as the oracle
+    restates it (726 entries, 364 of them the wrapper's aliases, 39 635 906 parameters = torchvision's
+    DeepLabV3-ResNet50 without the aux head, with the 1-channel stem and the 2-class classifier), and the host-side
+    geometry of the dilated convolutions (live taps, out-of-bounds flag) is what the layer shapes imply."""
+    from insar_unet_ca_amd import deeplab
+    from oracle import deeplab_oracle as dlo
+    net = iu.DeepLabV3_SingleChannel_Attn(num_classes=2, backbone="resnet50", pretrained=False)
+    sd, tmpl = net.state_dict(), dlo.state_dict_template(2)
+    assert list(sd.keys()) == list(tmpl.keys()) and len(sd) == 726
+    assert all(tuple(sd[k].shape) == tuple(tmpl[k].shape) for k in tmpl)
+    assert sum(p.numel() for p in net.parameters()) == 39635906
+    assert sd["backbone.layer3.0.downsample.0.weight"].data_ptr() == sd["model.backbone.layer3.0.downsample.0.weight"].data_ptr()
+    assert sd["upsample_conv.weight"].shape == (2, 256, 1, 1) and sd["model.backbone.conv1.weight"].shape == (64, 1, 7, 7)
+    with pytest.raises(ValueError):
+        iu.DeepLabV3_SingleChannel_Attn(backbone="vgg")
+    with pytest.raises(iu.InsarError, match="no CPU fallback"):
+        net(torch.zeros(1, 1, 64, 64))
+    # dilation / stride plan of the 16 bottlenecks (torchvision _make_layer with replace_stride_with_dilation)
+    specs = {s[0]: s[1:] for s in dlo.block_specs()}
+    assert specs["layer2.0"] == (256, 128, 2, 1, True) and specs["layer3.0"] == (512, 256, 1, 1, True)
+    assert specs["layer3.1"][3] == 2 and specs["layer4.0"][3] == 2 and specs["layer4.2"][3] == 4
+    # a tap is live when it reaches the interior for some output position
+    live = deeplab._live
+    assert live(8, 8, 1, 0) and live(8, 8, 1, -7) and not live(8, 8, 1, -8) and not live(8, 8, 1, 12)
+    assert live(32, 32, 1, 24) and not live(32, 32, 1, 36) and live(32, 64, 2, -1) and live(32, 64, 2, 1)
