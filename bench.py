@@ -81,7 +81,9 @@ def main() -> int:
     ap.add_argument("--batch", type=int, default=16, help="tiles per GPU (config 2: 16)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--loss", default="dice_ce", choices=["dice_ce", "ce"])
+    ap.add_argument("--loss", default=None, choices=["dice_ce", "ce"], help="default: dice_ce for unet (config 2), ce for deeplab")
+    ap.add_argument("--model", default="unet", choices=["unet", "deeplab"],
+                    help="unet = U-Net-CA (configs 2-4, the headline metric); deeplab = DeepLabV3-CA (config 5, 1-channel tiles)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--shard-optimizer", action="store_true",
                     help="N > 1: reduce-scatter + Adam on the 1/N shard + all-gather instead of all-reduce + full Adam")
@@ -117,8 +119,14 @@ def main() -> int:
             dist.init_process_group(args.backend)
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if args.loss is None:
+        args.loss = "dice_ce" if args.model == "unet" else "ce"
+    channels = 2 if args.model == "unet" else 1
     torch.manual_seed(0)                       # identical random init on every rank
-    net = iu.UNet(in_channels=2, num_classes=2, use_se=True, compute_dtype=dtype).to(dev).train()
+    if args.model == "unet":
+        net = iu.UNet(in_channels=2, num_classes=2, use_se=True, compute_dtype=dtype).to(dev).train()
+    else:
+        net = iu.DeepLabV3_SingleChannel_Attn(num_classes=2, backbone="resnet50", pretrained=False, compute_dtype=dtype).to(dev).train()
     model = net
     if world > 1:
         from insar_unet_ca_amd.parallel import DataParallel
@@ -134,7 +142,7 @@ def main() -> int:
     nb = 2
     batches = []
     for b in range(nb):
-        x, y = make_batch((rank * nb + b) * args.batch, args.batch, args.size)
+        x, y = make_batch((rank * nb + b) * args.batch, args.batch, args.size, channels=channels)
         batches.append((x.to(dev), y.to(dev)))
 
     def step(i: int):
@@ -190,24 +198,35 @@ def main() -> int:
         value = tiles / elapsed
         ms = 1e3 * elapsed / args.steps
         per_gpu = value / world
+        if args.model == "unet":
+            name, flop_tile = "U-Net-CA (in=2, classes=2, use_se)", FLOP_PER_TILE_256 * (args.size / 256) ** 2
+            act_bytes = (754e6 if args.dtype == "bf16" else 1508e6) * (args.size / 256) ** 2
+            nparams = 31261122
+        else:
+            # DeepLabV3-CA: algorithmic FLOPs from the layer shapes of the plan (every tap of every convolution, forward +
+            # input gradient + weight gradient; the 1-channel stem has no input gradient); no ideal-fusion byte model has
+            # been derived for it (SURVEY 8d covers the U-Net), so only the matrix-core position is reported
+            plan = next(iter(net._plans.plans.values()))[0]
+            macs = sum(u.M * u.cin * u.cout * u.k * u.k for u in plan.units) / args.batch
+            flop_tile = 3 * 2.0 * macs + 2 * 2.0 * (args.size // 2) ** 2 * 64 * 49
+            name, act_bytes, nparams = "DeepLabV3-CA (ResNet-50 os8 + ASPP + CAM, in=1, classes=2)", None, 39635906
         out = {
-            "metric": "InSAR tiles/sec (fwd+bwd) U-Net-CA 256x256", "value": round(value, 2), "unit": "tiles/s",
+            "metric": "InSAR tiles/sec (fwd+bwd) U-Net-CA 256x256" if args.model == "unet" else "InSAR tiles/sec (fwd+bwd) DeepLabV3-CA 256x256 (config 5)",
+            "value": round(value, 2), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"U-Net-CA (in=2, classes=2, use_se) {args.dtype}, batch {args.batch}x2x{args.size}x{args.size} "
+            "config": {"workload": f"{name} {args.dtype}, batch {args.batch}x{channels}x{args.size}x{args.size} "
                                    f"per GPU, {'Dice+CE' if args.loss == 'dice_ce' else 'CE'} + Adam(lr=1e-4) training on synthetic InSAR tiles",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "final_loss": round(final_loss, 5),
             "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 3),
             "hbm_allocated_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
         }
-        sz = (args.size / 256) ** 2
-        if args.dtype == "bf16":
-            peak, bytes_tile = PEAK_BF16_TFLOPS, (754e6 * sz + 1125e6 / args.batch)
-        else:
-            peak, bytes_tile = PEAK_F32_TFLOPS, (1508e6 * sz + 1250e6 / args.batch)
-        fl = per_gpu * FLOP_PER_TILE_256 * sz / 1e12
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        per_param = 36 if args.dtype == "bf16" else 40      # weights fwd + bwd, gradient write, Adam
+        bytes_tile = (act_bytes + per_param * nparams / args.batch) if act_bytes is not None else 0.0
+        fl = per_gpu * flop_tile / 1e12
         bw = per_gpu * bytes_tile / 1e9
         out["frac_of_mfma_roofline"] = round(fl / peak, 4)
         out["frac_of_hbm_roofline"] = round(bw / PEAK_HBM_GBS, 4)
@@ -215,8 +234,10 @@ def main() -> int:
         out["roofline_step"] = {"bound": bound, "achieved": round(fl if bound == "mfma" else bw, 2),
                                 "peak": peak if bound == "mfma" else PEAK_HBM_GBS, "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
                                 "frac": round(max(fl / peak, bw / PEAK_HBM_GBS), 4),
-                                "algorithmic": f"{FLOP_PER_TILE_256 * sz / 1e9:.1f} GFLOP and {bytes_tile / 1e6:.0f} MB per tile "
+                                "algorithmic": f"{flop_tile / 1e9:.1f} GFLOP and {bytes_tile / 1e6:.0f} MB per tile "
                                                "(SURVEY 8d), whole step incl. loss and Adam, timed region"}
+        if act_bytes is None:
+            out.pop("frac_of_hbm_roofline")
         if timers:
             summ = timers["timed_config"].summary()
             alone = timers["alone"].summary()
@@ -269,7 +290,7 @@ def main() -> int:
             out["gemm_total"] = total(summ, t_el)
             out["gemm_kernels_alone"] = table(alone, timers["alone"].elapsed)
             out["gemm_total_alone"] = total(alone, timers["alone"].elapsed)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "unet":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
