@@ -1,0 +1,199 @@
+"""Kernel-level GPU parity of csrc/deeplab.hip and the extended implicit-GEMM paths (dilated / strided convolutions,
+epilogue add, per-tap weight-gradient tables) against float64 torch on the kernels' own operands: tight (no ReLU
+decision involved), fp32 and bf16."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import max_rel
+
+pytestmark = pytest.mark.gpu
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1e-2}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm device")
+    from insar_unet_ca_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _act(x, dtype, dev):
+    from insar_unet_ca_amd import engine
+    b, c, h, w = x.shape
+    a = engine.Act.alloc(b, h, w, c, dtype, dev)
+    engine.pack_input(x.to(dev), a)
+    return a
+
+
+def _rnd(shape, seed, dtype):
+    x = torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+    return x.to(dtype).float() if dtype == torch.bfloat16 else x         # operands exactly representable in the compute type
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maxpool3s2_forward_and_backward(dev, dtype):
+    from insar_unet_ca_amd import _lib, engine
+    from insar_unet_ca_amd._lib import call, ptr
+    x = _rnd((2, 64, 12, 20), 1, dtype)
+    x[0, :, 0:3, 0:3] = 0.5                         # ties: the first maximum in scan order wins
+    xa = _act(x, dtype, dev)
+    ya = engine.Act.alloc(2, 6, 10, 64, dtype, dev)
+    arg = torch.zeros((2, 6, 10, 64), dtype=torch.uint8, device=dev)
+    call("insar_maxpool3s2_fwd", xa.ref, ya.ref, ptr(arg), _lib.stream_ptr())
+    xr = x.double().requires_grad_(True)
+    ref = F.max_pool2d(xr, 3, 2, 1)
+    assert torch.equal(ya.nchw().cpu().double(), ref.detach())
+    g = _rnd((2, 64, 6, 10), 2, dtype)
+    ga = _act(g, dtype, dev)
+    dxa = engine.Act.alloc(2, 12, 20, 64, dtype, dev)
+    call("insar_maxpool3s2_bwd", ga.ref, ptr(arg), dxa.ref, _lib.stream_ptr())
+    ref.backward(g.double())
+    assert max_rel(dxa.nchw(), xr.grad) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_residual_pooling_broadcast_dropout_kernels(dev, dtype):
+    from insar_unet_ca_amd import _lib, engine
+    from insar_unet_ca_amd._lib import call, ptr
+    s = _lib.stream_ptr()
+    B, Cn, H, W = 3, 128, 6, 10
+    y, res, dout = _rnd((B, Cn, H, W), 3, dtype), _rnd((B, Cn, H, W), 4, dtype), _rnd((B, Cn, H, W), 5, dtype)
+    scale, shift = torch.rand(Cn) + 0.5, torch.randn(Cn) * 0.1
+    ya, ra, da = _act(y, dtype, dev), _act(res, dtype, dev), _act(dout, dtype, dev)
+    out = engine.Act.alloc(B, H, W, Cn, dtype, dev)
+    call("insar_bn_add_relu", ya.ref, ptr(scale.to(dev)), ptr(shift.to(dev)), ra.ref, out.ref, 1, s)
+    ref = torch.relu(y.double() * scale.view(1, -1, 1, 1).double() + shift.view(1, -1, 1, 1).double() + res.double())
+    assert max_rel(out.nchw(), ref) <= TOL[dtype]
+    call("insar_relu_gate_bwd", da.ref, out.ref, da.ref, s)                  # in place
+    assert torch.equal(da.nchw().cpu(), torch.where(out.nchw().cpu() > 0, dout, torch.zeros_like(dout)))
+    # sum over the image and its adjoint
+    gp = engine.Act.alloc(B, 1, 1, Cn, dtype, dev)
+    call("insar_sum_hw", ya.ref, gp.ref, 1.0 / (H * W), s)
+    assert max_rel(gp.nchw(), y.double().mean((2, 3), keepdim=True)) <= TOL[dtype]
+    dst = _act(res, dtype, dev)
+    call("insar_broadcast_hw", gp.ref, dst.ref, 0.5, 1, s)
+    assert max_rel(dst.nchw(), res.double() + 0.5 * gp.nchw().cpu().double()) <= TOL[dtype]
+    call("insar_broadcast_hw", gp.ref, dst.ref, 1.0, 0, s)
+    assert torch.equal(dst.nchw().cpu(), gp.nchw().cpu().expand(B, Cn, H, W))
+    # dropout: the drawn mask is ~Bernoulli(1 - p), applied with 1/(1-p); a stored mask re-applies bit for bit
+    mask = torch.zeros((B, H, W, Cn), dtype=torch.uint8, device=dev)
+    dr = engine.Act.alloc(B, H, W, Cn, dtype, dev)
+    call("insar_dropout", ya.ref, dr.ref, ptr(mask), 1234, 0.5, 1, s)
+    m = mask.permute(0, 3, 1, 2).cpu()
+    assert 0.45 < float(m.float().mean()) < 0.55
+    assert max_rel(dr.nchw(), y.double() * m.double() * 2.0) <= TOL[dtype]
+    dr2 = engine.Act.alloc(B, H, W, Cn, dtype, dev)
+    call("insar_dropout", ya.ref, dr2.ref, ptr(mask), 0, 0.5, 0, s)
+    assert torch.equal(dr.nchw(), dr2.nchw())
+    mask2 = torch.zeros_like(mask)
+    call("insar_dropout", ya.ref, dr2.ref, ptr(mask2), 99, 0.5, 1, s)
+    assert not torch.equal(mask, mask2)
+
+
+@pytest.mark.parametrize("hw_in,hw_out", [((8, 8), (64, 64)), ((12, 20), (96, 160)), ((5, 7), (13, 30))])
+def test_bilinear_resize_and_its_adjoint(dev, hw_in, hw_out):
+    from insar_unet_ca_amd import _lib
+    from insar_unet_ca_amd._lib import call, ptr
+    x = torch.randn((3, 2) + hw_in, generator=torch.Generator().manual_seed(7))
+    out = torch.empty((3, 2) + hw_out, device=dev)
+    call("insar_bilinear_fwd", ptr(x.to(dev)), ptr(out), 6, hw_in[0], hw_in[1], hw_out[0], hw_out[1], _lib.stream_ptr())
+    xr = x.double().requires_grad_(True)
+    ref = F.interpolate(xr, size=hw_out, mode="bilinear", align_corners=False)
+    assert max_rel(out, ref.detach()) <= 2e-6
+    g = torch.randn((3, 2) + hw_out, generator=torch.Generator().manual_seed(8))
+    din = torch.empty((3, 2) + hw_in, device=dev)
+    call("insar_bilinear_bwd", ptr(g.to(dev)), ptr(din), 6, hw_in[0], hw_in[1], hw_out[0], hw_out[1], _lib.stream_ptr())
+    ref.backward(g.double())
+    assert max_rel(din, xr.grad) <= 2e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stem_conv7x7_forward_stats_and_weight_gradient(dev, dtype):
+    from insar_unet_ca_amd import _lib, engine
+    from insar_unet_ca_amd._lib import call, ptr
+    s = _lib.stream_ptr()
+    B, H, W = 2, 24, 40
+    x = _rnd((B, 1, H, W), 11, dtype)
+    w = _rnd((64, 1, 7, 7), 12, dtype) * 0.1
+    w = w.to(dtype).float() if dtype == torch.bfloat16 else w
+    ya = engine.Act.alloc(B, H // 2, W // 2, 64, dtype, dev)
+    rows = call("insar_conv7x7s2_fwd_rows", B, H)
+    stats = torch.zeros(rows, 2, 64, device=dev)
+    call("insar_conv7x7s2_fwd", ptr(x.to(dev)), H, W, ptr(w.to(dev)), ya.ref, ptr(stats), s)
+    ref = F.conv2d(x.double(), w.double(), None, stride=2, padding=3)
+    assert max_rel(ya.nchw(), ref) <= TOL[dtype]
+    stored = ya.nchw().double().cpu()
+    assert max_rel(stats.sum(0)[0], stored.sum((0, 2, 3))) <= 1e-5 and max_rel(stats.sum(0)[1], (stored ** 2).sum((0, 2, 3))) <= 1e-5
+    g = _rnd((B, 64, H // 2, W // 2), 13, dtype)
+    ga = _act(g, dtype, dev)
+    nb = call("insar_conv7x7s2_wgrad_blocks", B, H // 2)
+    part = torch.zeros(nb, 64 * 49, device=dev)
+    call("insar_conv7x7s2_wgrad", ptr(x.to(dev)), H, W, ga.ref, ptr(part), s)
+    wr = w.double().requires_grad_(True)
+    F.conv2d(x.double(), wr, None, stride=2, padding=3).backward(g.double())
+    assert max_rel(part.sum(0).view(64, 1, 7, 7), wr.grad) <= 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k,stride,dil,cin,cout,shape", [
+    (3, 1, 2, 64, 128, (2, 64, 8, 8)),        # dilation 2 on a small map: out-of-bounds taps, 128-row tiles
+    (3, 1, 4, 128, 64, (3, 128, 12, 20)),     # dilation 4, ragged map
+    (3, 1, 12, 64, 64, (2, 64, 16, 16)),      # ASPP rate 12 on 16 x 16: only a 4-wide band of each off-centre tap is live
+    (3, 1, 12, 64, 64, (1, 64, 8, 8)),        # rate 12 on 8 x 8: the centre tap alone (a 1x1 convolution)
+    (3, 1, 4, 64, 64, (16, 64, 32, 32)),      # 16384 pixels: the 256-row out-of-bounds variant
+    (3, 2, 1, 64, 128, (2, 64, 16, 24)),      # stride 2 (layer2.0.conv2): parity-class input gradient
+    (1, 2, 1, 128, 256, (2, 128, 16, 16)),    # 1x1 stride 2 (layer2.0.downsample)
+    (1, 1, 1, 256, 64, (2, 256, 8, 8)),       # plain 1x1
+    (1, 1, 1, 128, 64, (16, 128, 1, 1)),      # the pooling branch: a (B, 1, 1, C) map
+])
+def test_conv_unit_against_float64(dev, dtype, k, stride, dil, cin, cout, shape):
+    """ConvUnit's three GEMMs on their own operands: forward conv (raw output + BatchNorm partial sums), input gradient
+    (with and without the epilogue add), weight gradient."""
+    from insar_unet_ca_amd import _lib, engine
+    from insar_unet_ca_amd.deeplab import ConvUnit
+    from insar_unet_ca_amd.engine import GradSink
+    pad = dil if k == 3 else 0
+    conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=pad, dilation=dil, bias=False)
+    bn = torch.nn.BatchNorm2d(cout)
+    with torch.no_grad():
+        conv.weight.copy_(_rnd(tuple(conv.weight.shape), 21, dtype) * (1.0 / np.sqrt(cin * k * k)))
+        if dtype == torch.bfloat16:
+            conv.weight.copy_(conv.weight.to(dtype).float())
+    conv, bn = conv.to(dev), bn.to(dev)
+    ctx = engine.Ctx(dev, dtype)
+    x = _rnd(shape, 22, dtype)
+    xa = _act(x, dtype, dev)
+    u = ConvUnit(ctx, conv, bn, xa, None, True, "test")
+    u.forward(True)
+    ref = F.conv2d(x.double(), conv.weight.detach().cpu().double(), None, stride=stride, padding=pad, dilation=dil)
+    assert max_rel(u.y.nchw(), ref) <= TOL[dtype]
+    stored = u.y.nchw().double().cpu()
+    folded = u.stats.sum(0)
+    assert max_rel(folded[0], stored.sum((0, 2, 3))) <= 1e-4
+    # backward GEMMs on a given dy
+    g = _rnd(tuple(ref.shape), 23, dtype)
+    u.dy = _act(g, dtype, dev)
+    sink = GradSink(ctx, u.params())
+    gw = sink.view(conv.weight)
+    u._weight_grad(gw)
+    xr = x.double().requires_grad_(True)
+    wr = conv.weight.detach().cpu().double().requires_grad_(True)
+    F.conv2d(xr, wr, None, stride=stride, padding=pad, dilation=dil).backward(g.double())
+    assert max_rel(gw, wr.grad) <= (2e-5 if dtype == torch.float32 else 2e-5)      # operands exact, fp32 accumulation
+    dx = engine.Act.alloc(shape[0], shape[2], shape[3], cin, dtype, dev)
+    addend = _rnd(shape, 24, dtype)
+    if stride == 1 or k == 3:
+        u._input_grad(dx, None)
+        assert max_rel(dx.nchw(), xr.grad) <= TOL[dtype]
+    dx2 = _act(addend, dtype, dev)
+    u._input_grad(dx2, dx2)                                                       # in-place add
+    assert max_rel(dx2.nchw(), xr.grad + addend.double()) <= TOL[dtype]
+    # halos stay zero
+    t = dx2.buf.float().clone(); t[:, 1:-1, 1:-1] = 0
+    assert float(t.abs().max()) == 0.0
