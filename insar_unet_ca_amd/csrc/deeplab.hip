@@ -270,12 +270,15 @@ __global__ void maxpool3s2_fwd_kernel(ActView x, ActView y, uint8_t* __restrict_
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
           const int h = 2 * ho + ky - 1, w = 2 * wo + kx - 1;
-          if (h < 0 || h >= x.H || w < 0 || w >= x.W) continue;
+          const bool valid = (unsigned)h < (unsigned)x.H && (unsigned)w < (unsigned)x.W;
           float f[CH];
-          Chunk<T>::unpack(*dl_chunk<T>(x, n, h, w, cc), f);
+          Chunk<T>::unpack(*dl_chunk<T>(x, n, valid ? h : 0, valid ? w : 0, cc), f);      // clamped address, predicated use
 #pragma unroll
-          for (int j = 0; j < CH; ++j)
-            if (am[j] < 0 || f[j] > m[j] || (f[j] != f[j] && m[j] == m[j])) { m[j] = f[j]; am[j] = ky * 3 + kx; }
+          for (int j = 0; j < CH; ++j) {
+            const bool take = valid && (am[j] < 0 || f[j] > m[j] || (f[j] != f[j] && m[j] == m[j]));
+            m[j] = take ? f[j] : m[j];
+            am[j] = take ? ky * 3 + kx : am[j];
+          }
         }
       *dl_chunk_w<T>(y, n, ho, wo, cc) = Chunk<T>::pack(m);
       uint8_t* ap = arg + (((int64_t)n * y.H + ho) * y.W + wo) * y.c_len + cc * CH;

@@ -65,9 +65,10 @@ def test_residual_pooling_broadcast_dropout_kernels(dev, dtype):
     B, Cn, H, W = 3, 128, 6, 10
     y, res, dout = _rnd((B, Cn, H, W), 3, dtype), _rnd((B, Cn, H, W), 4, dtype), _rnd((B, Cn, H, W), 5, dtype)
     scale, shift = torch.rand(Cn) + 0.5, torch.randn(Cn) * 0.1
+    scale_d, shift_d = scale.to(dev), shift.to(dev)        # keep device operands alive: ptr() of a temporary dangles
     ya, ra, da = _act(y, dtype, dev), _act(res, dtype, dev), _act(dout, dtype, dev)
     out = engine.Act.alloc(B, H, W, Cn, dtype, dev)
-    call("insar_bn_add_relu", ya.ref, ptr(scale.to(dev)), ptr(shift.to(dev)), ra.ref, out.ref, 1, s)
+    call("insar_bn_add_relu", ya.ref, ptr(scale_d), ptr(shift_d), ra.ref, out.ref, 1, s)
     ref = torch.relu(y.double() * scale.view(1, -1, 1, 1).double() + shift.view(1, -1, 1, 1).double() + res.double())
     assert max_rel(out.nchw(), ref) <= TOL[dtype]
     call("insar_relu_gate_bwd", da.ref, out.ref, da.ref, s)                  # in place
@@ -102,13 +103,15 @@ def test_bilinear_resize_and_its_adjoint(dev, hw_in, hw_out):
     from insar_unet_ca_amd._lib import call, ptr
     x = torch.randn((3, 2) + hw_in, generator=torch.Generator().manual_seed(7))
     out = torch.empty((3, 2) + hw_out, device=dev)
-    call("insar_bilinear_fwd", ptr(x.to(dev)), ptr(out), 6, hw_in[0], hw_in[1], hw_out[0], hw_out[1], _lib.stream_ptr())
+    x_d = x.to(dev)
+    call("insar_bilinear_fwd", ptr(x_d), ptr(out), 6, hw_in[0], hw_in[1], hw_out[0], hw_out[1], _lib.stream_ptr())
     xr = x.double().requires_grad_(True)
     ref = F.interpolate(xr, size=hw_out, mode="bilinear", align_corners=False)
     assert max_rel(out, ref.detach()) <= 2e-6
     g = torch.randn((3, 2) + hw_out, generator=torch.Generator().manual_seed(8))
     din = torch.empty((3, 2) + hw_in, device=dev)
-    call("insar_bilinear_bwd", ptr(g.to(dev)), ptr(din), 6, hw_in[0], hw_in[1], hw_out[0], hw_out[1], _lib.stream_ptr())
+    g_d = g.to(dev)
+    call("insar_bilinear_bwd", ptr(g_d), ptr(din), 6, hw_in[0], hw_in[1], hw_out[0], hw_out[1], _lib.stream_ptr())
     ref.backward(g.double())
     assert max_rel(din, xr.grad) <= 2e-6
 
@@ -125,7 +128,8 @@ def test_stem_conv7x7_forward_stats_and_weight_gradient(dev, dtype):
     ya = engine.Act.alloc(B, H // 2, W // 2, 64, dtype, dev)
     rows = call("insar_conv7x7s2_fwd_rows", B, H)
     stats = torch.zeros(rows, 2, 64, device=dev)
-    call("insar_conv7x7s2_fwd", ptr(x.to(dev)), H, W, ptr(w.to(dev)), ya.ref, ptr(stats), s)
+    x_d, w_d = x.to(dev), w.to(dev)
+    call("insar_conv7x7s2_fwd", ptr(x_d), H, W, ptr(w_d), ya.ref, ptr(stats), s)
     ref = F.conv2d(x.double(), w.double(), None, stride=2, padding=3)
     assert max_rel(ya.nchw(), ref) <= TOL[dtype]
     stored = ya.nchw().double().cpu()
@@ -134,7 +138,7 @@ def test_stem_conv7x7_forward_stats_and_weight_gradient(dev, dtype):
     ga = _act(g, dtype, dev)
     nb = call("insar_conv7x7s2_wgrad_blocks", B, H // 2)
     part = torch.zeros(nb, 64 * 49, device=dev)
-    call("insar_conv7x7s2_wgrad", ptr(x.to(dev)), H, W, ga.ref, ptr(part), s)
+    call("insar_conv7x7s2_wgrad", ptr(x_d), H, W, ga.ref, ptr(part), s)
     wr = w.double().requires_grad_(True)
     F.conv2d(x.double(), wr, None, stride=2, padding=3).backward(g.double())
     assert max_rel(part.sum(0).view(64, 1, 7, 7), wr.grad) <= 2e-5
