@@ -436,7 +436,7 @@ extern "C" int insar_relu_gate_bwd(const InsarAct* dout, const InsarAct* out, co
 // global pooling over the image (AdaptiveAvgPool2d(1) of the ASPP pooling branch, and the adjoint of its broadcast):
 // out[n, 0, 0, c] = factor * sum_hw x[n, h, w, c]; out is a (B, 1, 1, C) slice. One block per (image, 64 channels).
 // ---------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, typename TO>
 __global__ void __launch_bounds__(DL_THREADS) sum_hw_kernel(ActView x, ActView out, float factor) {
   constexpr int CH = Chunk<T>::N;
   constexpr int CPB = 64 / CH;              // chunks per block (64 channels)
@@ -459,36 +459,39 @@ __global__ void __launch_bounds__(DL_THREADS) sum_hw_kernel(ActView x, ActView o
 #pragma unroll
   for (int j = 0; j < CH; ++j) red[threadIdx.x * CH + j] = acc[j];
   __syncthreads();
-  if (threadIdx.x < CPB) {
-    float tot[CH];
-#pragma unroll
-    for (int j = 0; j < CH; ++j) tot[j] = 0.f;
-    for (int p = 0; p < PL; ++p)
-#pragma unroll
-      for (int j = 0; j < CH; ++j) tot[j] += red[(p * CPB + threadIdx.x) * CH + j];
-#pragma unroll
-    for (int j = 0; j < CH; ++j) tot[j] *= factor;
-    *dl_chunk_w<T>(out, n, 0, 0, cb * CPB + threadIdx.x) = Chunk<T>::pack(tot);
+  // one thread per output channel of the block's 64: fixed summation order over the pixel lanes
+  if (threadIdx.x < 64) {
+    const int c = threadIdx.x, chunk = c / CH, j = c % CH;
+    float tot = 0.f;
+    for (int p = 0; p < PL; ++p) tot += red[(p * CPB + chunk) * CH + j];
+    tot *= factor;
+    char* o = out.base + (out.elem_offset(n, 0, 0) + (int64_t)cb * 64 + c) * (int64_t)sizeof(TO);
+    if constexpr (sizeof(TO) == 2) *(uint16_t*)o = f32_to_bf16(tot);
+    else *(float*)o = tot;
   }
 }
 
+/* out may be fp32 while x is bf16: the pooled vector of the ASPP pooling branch is kept in fp32 (its sample-to-sample
+ * spread is far below bf16's resolution of its mean, and the BatchNorm that follows divides by that spread). */
 extern "C" int insar_sum_hw(const InsarAct* x, const InsarAct* out, float factor, void* stream) {
   int rc;
   if ((rc = insar_check_act(x, "insar_sum_hw", "x"))) return rc;
   if ((rc = insar_check_act(out, "insar_sum_hw", "out"))) return rc;
-  if (out->B != x->B || out->H != 1 || out->W != 1 || out->c_len != x->c_len || out->dtype != x->dtype || x->c_len % 64)
+  if (out->B != x->B || out->H != 1 || out->W != 1 || out->c_len != x->c_len || x->c_len % 64)
     INSAR_FAIL(INSAR_E_SHAPE, "insar_sum_hw: out must be the (B, 1, 1, C) slice of x's channels (C %% 64 == 0)");
+  if (out->dtype != x->dtype && out->dtype != INSAR_F32) INSAR_FAIL(INSAR_E_DTYPE, "insar_sum_hw: out must have x's dtype or be fp32");
   const int grid = x->B * (x->c_len / 64);
   hipStream_t s = (hipStream_t)stream;
-  if (x->dtype == INSAR_BF16) hipLaunchKernelGGL(sum_hw_kernel<bf16_t>, dim3(grid), dim3(DL_THREADS), 0, s, make_view(*x), make_view(*out), factor);
-  else hipLaunchKernelGGL(sum_hw_kernel<float>, dim3(grid), dim3(DL_THREADS), 0, s, make_view(*x), make_view(*out), factor);
+  if (x->dtype == INSAR_BF16 && out->dtype == INSAR_BF16) hipLaunchKernelGGL((sum_hw_kernel<bf16_t, bf16_t>), dim3(grid), dim3(DL_THREADS), 0, s, make_view(*x), make_view(*out), factor);
+  else if (x->dtype == INSAR_BF16) hipLaunchKernelGGL((sum_hw_kernel<bf16_t, float>), dim3(grid), dim3(DL_THREADS), 0, s, make_view(*x), make_view(*out), factor);
+  else hipLaunchKernelGGL((sum_hw_kernel<float, float>), dim3(grid), dim3(DL_THREADS), 0, s, make_view(*x), make_view(*out), factor);
   INSAR_CHECK_LAUNCH("insar_sum_hw");
   return INSAR_OK;
 }
 
 // dst[n,h,w,c] = (accumulate ? dst : 0) + factor * src[n,0,0,c]: bilinear up-sampling of a 1x1 map (forward of the pooling
 // branch, accumulate = 0) and the gradient of the global average (accumulate = 1, factor = 1/HW).
-template <typename T>
+template <typename T, typename TS>
 __global__ void broadcast_hw_kernel(ActView src, ActView dst, float factor, int accumulate) {
   constexpr int CH = Chunk<T>::N;
   const int cpp = dst.c_len / CH;
@@ -498,7 +501,12 @@ __global__ void broadcast_hw_kernel(ActView src, ActView dst, float factor, int 
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
       const int w = e / cpp, cc = e - w * cpp;
       float f[CH], d[CH];
-      Chunk<T>::unpack(*dl_chunk<T>(src, n, 0, 0, cc), f);
+      const char* sp = src.base + (src.elem_offset(n, 0, 0) + (int64_t)cc * CH) * (int64_t)sizeof(TS);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        if constexpr (sizeof(TS) == 2) f[j] = bf16_to_f32(((const uint16_t*)sp)[j]);
+        else f[j] = ((const float*)sp)[j];
+      }
       if (accumulate) {
         Chunk<T>::unpack(*dl_chunk<T>(dst, n, h, w, cc), d);
 #pragma unroll
@@ -512,16 +520,19 @@ __global__ void broadcast_hw_kernel(ActView src, ActView dst, float factor, int 
   }
 }
 
+/* src may be fp32 while dst is bf16 (see insar_sum_hw). */
 extern "C" int insar_broadcast_hw(const InsarAct* src, const InsarAct* dst, float factor, int32_t accumulate, void* stream) {
   int rc;
   if ((rc = insar_check_act(src, "insar_broadcast_hw", "src"))) return rc;
   if ((rc = insar_check_act(dst, "insar_broadcast_hw", "dst"))) return rc;
-  if (src->B != dst->B || src->H != 1 || src->W != 1 || src->c_len != dst->c_len || src->dtype != dst->dtype)
+  if (src->B != dst->B || src->H != 1 || src->W != 1 || src->c_len != dst->c_len)
     INSAR_FAIL(INSAR_E_SHAPE, "insar_broadcast_hw: src must be the (B, 1, 1, C) slice of dst's channels");
+  if (src->dtype != dst->dtype && src->dtype != INSAR_F32) INSAR_FAIL(INSAR_E_DTYPE, "insar_broadcast_hw: src must have dst's dtype or be fp32");
   int grid = insar_grid_cap((int64_t)dst->B * dst->H);
   hipStream_t s = (hipStream_t)stream;
-  if (dst->dtype == INSAR_BF16) hipLaunchKernelGGL(broadcast_hw_kernel<bf16_t>, dim3(grid), dim3(DL_THREADS), 0, s, make_view(*src), make_view(*dst), factor, accumulate);
-  else hipLaunchKernelGGL(broadcast_hw_kernel<float>, dim3(grid), dim3(DL_THREADS), 0, s, make_view(*src), make_view(*dst), factor, accumulate);
+  if (dst->dtype == INSAR_BF16 && src->dtype == INSAR_BF16) hipLaunchKernelGGL((broadcast_hw_kernel<bf16_t, bf16_t>), dim3(grid), dim3(DL_THREADS), 0, s, make_view(*src), make_view(*dst), factor, accumulate);
+  else if (dst->dtype == INSAR_BF16) hipLaunchKernelGGL((broadcast_hw_kernel<bf16_t, float>), dim3(grid), dim3(DL_THREADS), 0, s, make_view(*src), make_view(*dst), factor, accumulate);
+  else hipLaunchKernelGGL((broadcast_hw_kernel<float, float>), dim3(grid), dim3(DL_THREADS), 0, s, make_view(*src), make_view(*dst), factor, accumulate);
   INSAR_CHECK_LAUNCH("insar_broadcast_hw");
   return INSAR_OK;
 }

@@ -429,8 +429,14 @@ class DeepLabPlan:
         self.cat = A(h8, w8, 1280)
         self.branches = [ConvUnit(ctx, aspp.convs[i][0], aspp.convs[i][1], self.x5, self.cat.slice(256 * i, 256), True, f"aspp.convs.{i}")
                          for i in range(4)]
-        self.gp = A(1, 1, 2048)
-        self.pool_unit = ConvUnit(ctx, aspp.convs[4][1], aspp.convs[4][2], self.gp, None, True, "aspp.convs.4")
+        # The pooling branch runs in fp32 whatever the compute type (B x 2048 values): the pooled vectors of similar tiles
+        # differ by far less than bf16 resolves, and the BatchNorm behind the 1x1 conv divides by that spread.
+        self.ctx32 = ctx
+        if dtype != torch.float32:
+            self.ctx32 = Ctx(device, torch.float32)
+            self.ctx32.side = None               # its (tiny) weight gradient stays on the main stream
+        self.gp = Act.alloc(B, 1, 1, 2048, torch.float32, device)
+        self.pool_unit = ConvUnit(self.ctx32, aspp.convs[4][1], aspp.convs[4][2], self.gp, None, True, "aspp.convs.4")
         self.project = ConvUnit(ctx, aspp.project[0], aspp.project[1], self.cat, None, True, "aspp.project")
         self.drop_p = float(aspp.project[3].p)
         self.zdrop = A(h8, w8, 256)
@@ -489,7 +495,7 @@ class DeepLabPlan:
 
     def _grad(self, key: str, like: Act) -> Act:
         if key not in self._g:
-            self._g[key] = Act.alloc(like.B, like.H, like.W, like.c_len, self.ctx.dtype, self.ctx.device)
+            self._g[key] = Act.alloc(like.B, like.H, like.W, like.c_len, like.buf.dtype, self.ctx.device)
         return self._g[key]
 
     def _cam_desc(self) -> InsarCam:

@@ -219,7 +219,7 @@ class WeightSet:
                 a, b = w.param.shape[0], w.param.shape[1]
                 T = w.param.shape[2] * w.param.shape[3]
                 oab, oba = (w._buf["fwd"], w._buf["dgrad"]) if w.kind == "conv3" else (w._buf["dgrad"], w._buf["fwd"])
-                rows.append([w.master().data_ptr(), oab.data_ptr(), oba.data_ptr(), a, b, T, tile0, self.ctx.code])
+                rows.append([w.master().data_ptr(), oab.data_ptr(), oba.data_ptr(), a, b, T, tile0, w.ctx.code])
                 tile0 += ((a + 31) // 32) * ((b + 31) // 32)
             self._jobs = torch.tensor(rows, dtype=torch.int64).to(self.ctx.device)
             self._ptrs, self._total = ptrs, tile0

@@ -200,36 +200,44 @@ def test_deeplab_dropout_under_a_given_mask_and_adam_steps(dev):
 
 
 def test_deeplab_bf16_config5_geometry(dev):
-    """BASELINE.json config 5: DeepLabV3-CA bf16, batch 16 of 1 x 256 x 256: runs, is finite, tracks the fp32 HIP path
-    (bf16 storage, fp32 accumulation / statistics), is bitwise reproducible, and trains."""
+    """BASELINE.json config 5: DeepLabV3-CA bf16, batch 16 of 1 x 256 x 256.
+    Numerical contract: in EVAL mode (BatchNorm on running statistics) bf16 tracks the fp32 HIP path within the bf16
+    gate. In TRAINING mode at random initialisation the 53-layer network is chaotic in ANY precision — the fp32 forward
+    amplifies its own 6e-8 rounding to 1.3e-4 at the logits (2000x, test above, measured against float64), so bf16's
+    4e-3 rounding saturates (measured 0.39 rel-L2 at the logits, growing x1.2 per bottleneck; tools/debug_deeplab_bf16.py)
+    — so there the test checks what does hold: finite, bitwise reproducible, the loss at the fp32 value, and training."""
     import insar_unet_ca_amd as iu
     from insar_unet_ca_amd.data import make_batch
     x, y = make_batch(0, 16, 256, channels=1)
     x, y = x.to(dev), y.to(dev)
+    crit = iu.CrossEntropyLoss(ignore_index=255)
     net32, _ = _make(dev, 41, p_drop=0.0)
-    net32.train()
-    ref = net32(x).detach()
+    with torch.no_grad():
+        ref_eval = net32.eval()(x).detach()
+    ref_train_loss = float(crit(net32.train()(x), y))
     net32._plans.clear()
     del net32
     torch.cuda.empty_cache()
     net, _ = _make(dev, 41, dtype=torch.bfloat16, p_drop=0.0)
+    with torch.no_grad():
+        got_eval = net.eval()(x)
+    err = max_rel(got_eval, ref_eval)
+    agree = (got_eval.argmax(1) == ref_eval.argmax(1)).float().mean().item()
+    print(f"config 5 bf16 vs fp32 HIP, eval mode: max-rel {err:.3e}, arg-max agreement {agree:.4f}")
+    assert err <= 0.1 and agree >= 0.97
     net.train()
-    crit = iu.CrossEntropyLoss(ignore_index=255)
     opt = iu.Adam(net.parameters(), lr=1e-4)
-    logits = net(x)
-    err = max_rel(logits, ref)
-    agree = (logits.argmax(1) == ref.argmax(1)).float().mean().item()
-    print(f"config 5 bf16 vs fp32 HIP: max-rel {err:.3e}, arg-max agreement {agree:.4f}")
-    assert err <= 0.15 and agree >= 0.97
     opt.zero_grad()
-    l1 = crit(logits, y)
+    l1 = crit(net(x), y)
     l1.backward()
     g1 = [p.grad.clone() for p in net.parameters()]
     opt.zero_grad()
     l2 = crit(net(x), y)
     l2.backward()
+    print(f"config 5 training-mode loss: bf16 {float(l1):.5f}, fp32 {ref_train_loss:.5f}")
     assert float(l1) == float(l2) and all(torch.equal(a, p.grad) for a, p in zip(g1, net.parameters()))
     assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+    assert abs(float(l1) - ref_train_loss) <= 0.05 * ref_train_loss
     first = float(l2)
     for _ in range(6):
         opt.zero_grad()
