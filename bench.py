@@ -87,6 +87,9 @@ def main() -> int:
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--shard-optimizer", action="store_true",
                     help="N > 1: reduce-scatter + Adam on the 1/N shard + all-gather instead of all-reduce + full Adam")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the step from a captured hipGraph (insar_unet_ca_amd.GraphedTrainStep); auto = on for 1 GPU, off "
+                         "under data parallelism (the RCCL collectives inside backward are issued eagerly)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -153,16 +156,31 @@ def main() -> int:
         opt.step()
         return loss
 
+    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
+    if use_graph and world > 1:
+        print("error: --graph on is not available under data parallelism", file=sys.stderr)
+        return 2
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    timed_step = step
+    if use_graph:
+        gstep = iu.GraphedTrainStep(model, crit, opt, batches[0][0], batches[0][1], warmup=2)
+
+        def timed_step(i: int):
+            x, y = batches[i % nb]
+            return gstep(x, y)
+
+        for i in range(2):
+            timed_step(i)
+        torch.cuda.synchronize()
 
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = step(i)
+        loss = timed_step(i)
     host_enqueue = time.perf_counter() - t0      # host time to enqueue the K steps (no sync inside a step)
     torch.cuda.synchronize()
     if world > 1:
@@ -219,7 +237,7 @@ def main() -> int:
             "config": {"workload": f"{name} {args.dtype}, batch {args.batch}x{channels}x{args.size}x{args.size} "
                                    f"per GPU, {'Dice+CE' if args.loss == 'dice_ce' else 'CE'} + Adam(lr=1e-4) training on synthetic InSAR tiles",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
-            "final_loss": round(final_loss, 5),
+            "final_loss": round(final_loss, 5), "hipgraph": bool(use_graph),
             "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 3),
             "hbm_allocated_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
         }

@@ -420,10 +420,17 @@ int insar_relu_gate_bwd(const InsarAct* dout, const InsarAct* out, const InsarAc
 int insar_sum_hw(const InsarAct* x, const InsarAct* out, float factor, void* stream);
 int insar_broadcast_hw(const InsarAct* src, const InsarAct* dst, float factor, int32_t accumulate, void* stream);
 /* Dropout(p): make_mask != 0 draws mask[B][H][W][c_len] from (seed, element index) and stores it; == 0 applies `mask`. */
-int insar_dropout(const InsarAct* x, const InsarAct* dst, uint8_t* mask, uint64_t seed, float p, int32_t make_mask, void* stream);
+int insar_dropout(const InsarAct* x, const InsarAct* dst, uint8_t* mask, uint64_t seed, const int64_t* counter /*nullable, device:
+                  mixed into the seed so that every replay of a captured step draws a new mask*/, float p, int32_t make_mask, void* stream);
 /* F_T.resize(x, size, BILINEAR) (:160): bilinear, align_corners = False, on `planes` fp32 maps; and its adjoint. */
 int insar_bilinear_fwd(const float* in, float* out, int32_t planes, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, void* stream);
 int insar_bilinear_bwd(const float* dout, float* din, int32_t planes, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, void* stream);
+
+/* The same update with the step count and the bias corrections kept on the device: state = float[4] {t, 1-beta1^t,
+ * sqrt(1-beta2^t), -}. The call first advances t by one (a one-thread launch), then updates the parameters; nothing
+ * in the launch arguments changes from step to step, so a captured hipGraph of the training step can be replayed. */
+int insar_adam_step_dev(const int64_t* table, const int32_t* chunks, int32_t nchunks, int32_t chunk_elems,
+                        float lr, double beta1, double beta2, float eps, float* state, float grad_scale, void* stream);
 
 /* ---- small helpers ---------------------------------------------------------------------------- */
 int insar_scale_f32(float* p, int64_t n, float s, void* stream);

@@ -6,8 +6,9 @@ from .loss import CrossEntropyLoss, DiceCELoss, DiceLoss  # noqa: F401
 from .modules import ChannelAttentionModule, DoubleConv, MaxPool2d, SELayer, UNet  # noqa: F401
 from .deeplab import DeepLabV3_SingleChannel_Attn  # noqa: F401
 from .optim import Adam  # noqa: F401
+from .graph import GraphedTrainStep  # noqa: F401
 from .train import compute_metrics, save_history, train_model, validate_model  # noqa: F401
 
-__all__ = ["UNet", "DeepLabV3_SingleChannel_Attn", "DoubleConv", "SELayer", "ChannelAttentionModule", "MaxPool2d", "CrossEntropyLoss", "DiceLoss", "DiceCELoss", "Adam",
+__all__ = ["UNet", "DeepLabV3_SingleChannel_Attn", "DoubleConv", "SELayer", "ChannelAttentionModule", "MaxPool2d", "CrossEntropyLoss", "DiceLoss", "DiceCELoss", "Adam", "GraphedTrainStep",
            "compute_metrics", "train_model", "validate_model", "save_history", "VOCSegDataset", "SyntheticTiles",
            "ShardedSampler", "make_loader", "reference_transforms", "InsarError", "LIB_PATH"]

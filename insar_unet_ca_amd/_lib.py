@@ -146,6 +146,7 @@ _SIGNATURES = {
     "insar_confusion": [_P, _P, _I, _I, _L, _L, _P, _P],
     "insar_adam_step": [_P, _P, _I, _I, _F, _F, _F, _F, _F, _F, _F, _P],
     "insar_scale_f32": [_P, _L, _F, _P],
+    "insar_adam_step_dev": [_P, _P, _I, _I, _F, C.c_double, C.c_double, _F, _P, _F, _P],
     "insar_pixel_table_taps": [_P, _L, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "insar_conv7x7s2_fwd_rows": [_I, _I],
     "insar_conv7x7s2_fwd": [_P, _I, _I, _P, _AP, _P, _P],
@@ -157,7 +158,7 @@ _SIGNATURES = {
     "insar_relu_gate_bwd": [_AP, _AP, _AP, _P],
     "insar_sum_hw": [_AP, _AP, _F, _P],
     "insar_broadcast_hw": [_AP, _AP, _F, _I, _P],
-    "insar_dropout": [_AP, _AP, _P, C.c_uint64, _F, _I, _P],
+    "insar_dropout": [_AP, _AP, _P, C.c_uint64, _P, _F, _I, _P],
     "insar_bilinear_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "insar_bilinear_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],
 }

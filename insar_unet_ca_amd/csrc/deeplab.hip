@@ -550,8 +550,9 @@ __device__ __forceinline__ uint32_t dl_hash(uint64_t seed, uint64_t i) {
 }
 
 template <typename T>
-__global__ void dropout_kernel(ActView x, ActView dst, uint8_t* __restrict__ mask, uint64_t seed, float p, float inv_keep,
-                               int make_mask) {
+__global__ void dropout_kernel(ActView x, ActView dst, uint8_t* __restrict__ mask, uint64_t seed, const int64_t* __restrict__ counter,
+                               float p, float inv_keep, int make_mask) {
+  if (counter) seed = ((uint64_t)dl_hash(seed, (uint64_t)*counter) << 32) | dl_hash(seed ^ 0x5851F42D4C957F2Dull, (uint64_t)*counter);
   constexpr int CH = Chunk<T>::N;
   const int cpp = x.c_len / CH;
   const int total = x.W * cpp;
@@ -577,8 +578,8 @@ __global__ void dropout_kernel(ActView x, ActView dst, uint8_t* __restrict__ mas
 
 /* make_mask != 0: draw the mask from (seed, element index) and store it; == 0: apply the stored mask (backward, or a
  * forward under a mask supplied by the caller). */
-extern "C" int insar_dropout(const InsarAct* x, const InsarAct* dst, uint8_t* mask, uint64_t seed, float p, int32_t make_mask,
-                             void* stream) {
+extern "C" int insar_dropout(const InsarAct* x, const InsarAct* dst, uint8_t* mask, uint64_t seed, const int64_t* counter, float p,
+                             int32_t make_mask, void* stream) {
   int rc;
   if ((rc = insar_check_act(x, "insar_dropout", "x"))) return rc;
   if ((rc = insar_check_act(dst, "insar_dropout", "dst"))) return rc;
@@ -588,8 +589,8 @@ extern "C" int insar_dropout(const InsarAct* x, const InsarAct* dst, uint8_t* ma
   int grid = insar_grid_cap((int64_t)x->B * x->H);
   hipStream_t s = (hipStream_t)stream;
   const float inv_keep = 1.f / (1.f - p);
-  if (x->dtype == INSAR_BF16) hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(grid), dim3(DL_THREADS), 0, s, make_view(*x), make_view(*dst), mask, seed, p, inv_keep, make_mask);
-  else hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid), dim3(DL_THREADS), 0, s, make_view(*x), make_view(*dst), mask, seed, p, inv_keep, make_mask);
+  if (x->dtype == INSAR_BF16) hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(grid), dim3(DL_THREADS), 0, s, make_view(*x), make_view(*dst), mask, seed, counter, p, inv_keep, make_mask);
+  else hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid), dim3(DL_THREADS), 0, s, make_view(*x), make_view(*dst), mask, seed, counter, p, inv_keep, make_mask);
   INSAR_CHECK_LAUNCH("insar_dropout");
   return INSAR_OK;
 }

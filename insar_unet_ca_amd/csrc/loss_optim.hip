@@ -378,8 +378,16 @@ extern "C" int insar_confusion(const float* logits, const int64_t* target, int32
 //   m = m + (g - m)(1-b1);  v = b2 v + (1-b2) g^2;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 // 28 bytes of HBM traffic per parameter; 16-byte vector accesses on 16-byte aligned tensors.
 // ---------------------------------------------------------------------------------------------
+// DEV: the bias corrections come from device memory (state[1] = 1 - beta1^t, state[2] = sqrt(1 - beta2^t), written by
+// adam_advance_kernel), so that a captured hipGraph of the training step stays valid from one replay to the next.
+template <bool DEV>
 __global__ void adam_kernel(const int64_t* __restrict__ table, const int32_t* __restrict__ chunks, int chunk_elems,
-                            float lr_over_bc1, float b1, float b2, float eps, float inv_bc2_sqrt, float gscale) {
+                            float lr_over_bc1, float b1, float b2, float eps, float inv_bc2_sqrt, float gscale,
+                            const float* __restrict__ state) {
+  if constexpr (DEV) {
+    lr_over_bc1 = lr_over_bc1 / state[1];          // the host passes lr here
+    inv_bc2_sqrt = 1.f / state[2];
+  }
   const int ti = chunks[2 * blockIdx.x], ci = chunks[2 * blockIdx.x + 1];
   float* p = (float*)table[5 * ti + 0];
   const float* g = (const float*)table[5 * ti + 1];
@@ -427,8 +435,27 @@ extern "C" int insar_adam_step(const int64_t* table, const int32_t* chunks, int3
                                float grad_scale, void* stream) {
   if (!table || !chunks) INSAR_FAIL(INSAR_E_ARG, "insar_adam_step: null pointer");
   if (nchunks < 1 || chunk_elems < 4 || (chunk_elems & 3)) INSAR_FAIL(INSAR_E_SHAPE, "insar_adam_step: bad chunking");
-  hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, table, chunks, chunk_elems,
-                     lr / bias_correction1, beta1, beta2, eps, 1.f / bias_correction2_sqrt, grad_scale);
+  hipLaunchKernelGGL(adam_kernel<false>, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, table, chunks, chunk_elems,
+                     lr / bias_correction1, beta1, beta2, eps, 1.f / bias_correction2_sqrt, grad_scale, (const float*)nullptr);
   INSAR_CHECK_LAUNCH("insar_adam_step");
+  return INSAR_OK;
+}
+
+// state: float[4] = {t, 1 - beta1^t, sqrt(1 - beta2^t), unused}; t counts the steps taken (exact up to 2^24)
+__global__ void adam_advance_kernel(float* state, double b1, double b2) {
+  const double t = (double)state[0] + 1.0;
+  state[0] = (float)t;
+  state[1] = (float)(1.0 - pow(b1, t));
+  state[2] = (float)sqrt(1.0 - pow(b2, t));
+}
+
+extern "C" int insar_adam_step_dev(const int64_t* table, const int32_t* chunks, int32_t nchunks, int32_t chunk_elems, float lr,
+                                   double beta1, double beta2, float eps, float* state, float grad_scale, void* stream) {
+  if (!table || !chunks || !state) INSAR_FAIL(INSAR_E_ARG, "insar_adam_step_dev: null pointer");
+  if (nchunks < 1 || chunk_elems < 4 || (chunk_elems & 3)) INSAR_FAIL(INSAR_E_SHAPE, "insar_adam_step_dev: bad chunking");
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, beta1, beta2);
+  hipLaunchKernelGGL(adam_kernel<true>, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, table, chunks, chunk_elems,
+                     lr, (float)beta1, (float)beta2, eps, 1.f, grad_scale, (const float*)state);
+  INSAR_CHECK_LAUNCH("insar_adam_step_dev");
   return INSAR_OK;
 }

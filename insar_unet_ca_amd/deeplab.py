@@ -442,6 +442,8 @@ class DeepLabPlan:
         self.zdrop = A(h8, w8, 256)
         self.drop_mask = torch.zeros((B, h8, w8, 256), dtype=torch.uint8, device=device)
         self.drop_active = False
+        self.drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self.drop_counter = torch.zeros(1, dtype=torch.int64, device=device)
         self.external_mask = False        # tests: apply a caller-supplied mask instead of drawing one
         # head: 3x3 conv + BN + ReLU (post_aspp_conv), ChannelAttentionModule, 1x1 classifier, bilinear resize
         self.head = ConvUnit(ctx, head[1], head[2], self.zdrop, None, True, "classifier.1")
@@ -551,9 +553,11 @@ class DeepLabPlan:
         self.project.forward(training)
         self.drop_active = training and self.drop_p > 0.0
         if self.drop_active:
-            seed = 0 if self.external_mask else int(torch.randint(0, 2 ** 62, (1,)).item())
-            call("insar_dropout", self.project.out.ref, self.zdrop.ref, ptr(self.drop_mask), seed, self.drop_p,
-                 0 if self.external_mask else 1, s)
+            # mask = hash(seed drawn once from torch's RNG, device-side forward counter, element index): a new mask every
+            # training forward, also when the step is replayed from a captured hipGraph
+            self.drop_counter.add_(1)
+            call("insar_dropout", self.project.out.ref, self.zdrop.ref, ptr(self.drop_mask), self.drop_seed, ptr(self.drop_counter),
+                 self.drop_p, 0 if self.external_mask else 1, s)
             self.head.x = self.zdrop
         else:
             self.head.x = self.project.out
@@ -597,7 +601,7 @@ class DeepLabPlan:
             on_bucket(self, ("head", 0))
         if self.drop_active:
             dproj = self._grad("dproj", self.project.out)
-            call("insar_dropout", dzdrop.ref, dproj.ref, ptr(self.drop_mask), 0, self.drop_p, 0, s)
+            call("insar_dropout", dzdrop.ref, dproj.ref, ptr(self.drop_mask), 0, 0, self.drop_p, 0, s)
         else:
             dproj = dzdrop
         dcat = self._grad("dcat", self.cat)

@@ -869,7 +869,10 @@ class OutConvPlan:
 
         if dx is None:
             if self.ctx.side is not None and not (PROFILER is not None and PROFILER.alone) and dlogits.is_cuda:
-                dlogits.record_stream(self.ctx.side)      # read on the side stream after the caller has dropped it
+                if torch.cuda.is_current_stream_capturing():
+                    self._keep = dlogits                  # a graph's private pool: keep the buffer alive instead
+                else:
+                    dlogits.record_stream(self.ctx.side)  # read on the side stream after the caller has dropped it
             with self.ctx.side_stream():
                 if self.fused_src is not None:       # the input activation was never stored: recompute it from y
                     unit, gate = self.fused_src

@@ -20,6 +20,43 @@ class Adam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False, fused=False)
         self._tables = {}
         self.grad_scale = 1.0      # multiplies every gradient inside the kernel (DP pre-scaling)
+        self._dev_state = None     # float[4] on the device: step count + bias corrections (enable_device_step)
+        self._dev_pending = 0      # steps taken on the device that state['step'] has not been told about yet
+
+    # ---- device-side step count (hipGraph capture) ---------------------------------------------------------
+    def enable_device_step(self) -> None:
+        """Keep the step count and the bias corrections in device memory (insar_adam_step_dev): the launch arguments of
+        `step()` then never change, which is what a captured hipGraph of the training step needs. The arithmetic is the
+        same (bias corrections computed in double, rounded to fp32: bitwise the eager path's parameters). Requires every
+        parameter to share one step count; `state_dict()` still reports torch.optim.Adam's per-parameter `step`."""
+        if self._dev_state is not None:
+            return
+        steps, dev = set(), None
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p, {})
+                steps.add(float(st["step"]) if "step" in st else 0.0)
+                dev = p.device
+        if len(steps) > 1:
+            raise _lib.InsarError("Adam.enable_device_step: parameters have different step counts")
+        if len({tuple(g["betas"]) for g in self.param_groups}) > 1:
+            raise _lib.InsarError("Adam.enable_device_step: one (beta1, beta2) for all parameter groups")
+        t = steps.pop() if steps else 0.0
+        b1, b2 = self.param_groups[0]["betas"]
+        self._dev_state = torch.tensor([t, 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t), 0.0], dtype=torch.float32).to(dev)
+
+    def _sync_host_steps(self) -> None:
+        if self._dev_pending:
+            for group in self.param_groups:
+                for p in group["params"]:
+                    st = self.state.get(p)
+                    if st is not None and "step" in st:
+                        st["step"] += self._dev_pending
+            self._dev_pending = 0
+
+    def state_dict(self):
+        self._sync_host_steps()
+        return super().state_dict()
 
     def _table(self, key, tensors):
         hit = self._tables.get(key)
@@ -50,6 +87,18 @@ class Adam(torch.optim.Adam):
             if not params:
                 continue
             b1, b2 = group["betas"]
+            if self._dev_state is not None:
+                tensors = []
+                for p, g, m, v in zip(params, grads, exp_avgs, exp_avg_sqs):
+                    if not p.is_cuda or p.dtype != torch.float32 or g.dtype != torch.float32 or not p.is_contiguous() or not g.is_contiguous():
+                        raise _lib.InsarError("Adam HIP path: contiguous float32 ROCm parameters and gradients only")
+                    tensors.append((p, g, m, v))
+                key = tuple(x.data_ptr() for tup in tensors for x in tup)
+                table, chunk_t, nchunks = self._table(key, tensors)
+                call("insar_adam_step_dev", ptr(table), ptr(chunk_t), nchunks, CHUNK, float(group["lr"]), float(b1), float(b2),
+                     float(group["eps"]), ptr(self._dev_state), float(self.grad_scale), _lib.stream_ptr())
+                torch._C._increment_version(params)
+                continue
             by_step = {}
             for p, g, m, v, st in zip(params, grads, exp_avgs, exp_avg_sqs, steps):
                 if not p.is_cuda:
@@ -66,4 +115,6 @@ class Adam(torch.optim.Adam):
                 call("insar_adam_step", ptr(table), ptr(chunk_t), nchunks, CHUNK, float(group["lr"]), float(b1), float(b2),
                      float(group["eps"]), bc1, bc2_sqrt, float(self.grad_scale), _lib.stream_ptr())
                 torch._C._increment_version([p for p, _, _, _ in tensors])
+        if self._dev_state is not None:
+            self._dev_pending += 1
         return loss

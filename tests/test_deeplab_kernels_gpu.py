@@ -85,16 +85,23 @@ def test_residual_pooling_broadcast_dropout_kernels(dev, dtype):
     # dropout: the drawn mask is ~Bernoulli(1 - p), applied with 1/(1-p); a stored mask re-applies bit for bit
     mask = torch.zeros((B, H, W, Cn), dtype=torch.uint8, device=dev)
     dr = engine.Act.alloc(B, H, W, Cn, dtype, dev)
-    call("insar_dropout", ya.ref, dr.ref, ptr(mask), 1234, 0.5, 1, s)
+    call("insar_dropout", ya.ref, dr.ref, ptr(mask), 1234, 0, 0.5, 1, s)
     m = mask.permute(0, 3, 1, 2).cpu()
     assert 0.45 < float(m.float().mean()) < 0.55
     assert max_rel(dr.nchw(), y.double() * m.double() * 2.0) <= TOL[dtype]
     dr2 = engine.Act.alloc(B, H, W, Cn, dtype, dev)
-    call("insar_dropout", ya.ref, dr2.ref, ptr(mask), 0, 0.5, 0, s)
+    call("insar_dropout", ya.ref, dr2.ref, ptr(mask), 0, 0, 0.5, 0, s)
     assert torch.equal(dr.nchw(), dr2.nchw())
     mask2 = torch.zeros_like(mask)
-    call("insar_dropout", ya.ref, dr2.ref, ptr(mask2), 99, 0.5, 1, s)
+    call("insar_dropout", ya.ref, dr2.ref, ptr(mask2), 99, 0, 0.5, 1, s)
     assert not torch.equal(mask, mask2)
+    # a device-side counter mixed into the seed: same host arguments, another mask per counter value
+    counter = torch.ones(1, dtype=torch.int64, device=dev)
+    mask3, mask4 = torch.zeros_like(mask), torch.zeros_like(mask)
+    call("insar_dropout", ya.ref, dr2.ref, ptr(mask3), 1234, ptr(counter), 0.5, 1, s)
+    counter.add_(1)
+    call("insar_dropout", ya.ref, dr2.ref, ptr(mask4), 1234, ptr(counter), 0.5, 1, s)
+    assert not torch.equal(mask3, mask4) and not torch.equal(mask3, mask) and 0.45 < float(mask4.float().mean()) < 0.55
 
 
 @pytest.mark.parametrize("hw_in,hw_out", [((8, 8), (64, 64)), ((12, 20), (96, 160)), ((5, 7), (13, 30))])
