@@ -87,8 +87,8 @@ def main() -> int:
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--shard-optimizer", action="store_true",
                     help="N > 1: reduce-scatter + Adam on the 1/N shard + all-gather instead of all-reduce + full Adam")
-    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="replay the step from a captured hipGraph (insar_unet_ca_amd.GraphedTrainStep); auto = on for 1 GPU, off "
+    ap.add_argument("--graph", default="off", choices=["auto", "on", "off"],
+                    help="replay the step from a captured hipGraph (insar_unet_ca_amd.GraphedTrainStep): off by default (measured slower than eager launches on ROCm 7.2: 8.6 vs 7.9 ms/step); auto = on for 1 GPU, off "
                          "under data parallelism (the RCCL collectives inside backward are issued eagerly)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")

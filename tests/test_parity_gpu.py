@@ -1134,53 +1134,41 @@ def test_train_loop_over_the_voc_reader(dev, tmp_path):
     assert (tmp_path / "best.pth").exists() and (tmp_path / "metrics" / "history.json").exists()
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_miou_parity_task(dev, dtype):
-    """north_star's mIoU clause at the resolution the task allows. tests/golden/g8b_miou_parity.json holds the
-    oracle's validation-mIoU curves on a 64x64 synthetic task (256 train / 256 held-out tiles, 12 epochs, same
-    tiles, order and initial weights as here, tests/tools/miou_parity.py) for the plain run and for two runs with
-    1e-6 relative noise on the training inputs: their last-4-epoch means are 0.549 / 0.581 / 0.569, i.e. the
-    reference algorithm itself is only reproducible to ~3 pt on this metric (Adam + ReLU/BN chaos, 3-8 %
-    positive pixels). The HIP path must land inside that band widened by 4 pt (round 1 on MI355X: fp32 0.580,
-    bf16 0.596) and reach the oracle's best validation loss (0.166-0.173; HIP 0.163 / 0.159)."""
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_miou_within_0p3_pt_of_the_reference(dev, dtype):
+    """north_star: "mIoU within 0.3 pt of the reference on identical splits".
+    tests/golden/g8c_miou_reference.json holds the held-out mIoU that the IMPORTED REFERENCE (its own UNet, train_model,
+    validate_model and compute_metrics, Unet-ChannalAttention.py:100-163, 215-399; torch CPU fp32, build container,
+    tests/tools/miou_experiment.py --side reference) reaches on the synthetic "bowl" task — 256 training tiles of 64 x 64,
+    batch 8, CE, Adam(lr 1e-4), 30 epochs, evaluated on 1024 held-out tiles — for several seeds; a seed fixes the initial
+    weights and the batch order. The HIP path runs the same protocol (insar_unet_ca_amd.train) with the same seeds.
+    The task converges (mIoU ~0.98, seed-to-seed std 0.13 pt), so tenths of a point resolve: the gate is that the 95 %
+    confidence interval of the PAIRED mean difference (Student t over the seeds) lies inside +-0.3 pt."""
     import json
     import os
-    import insar_unet_ca_amd as iu
-    from insar_unet_ca_amd.data import make_batch
-    from insar_unet_ca_amd.train import confusion_counts, metrics_from_counts
-    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g8b_miou_parity.json")))["runs"]
-    oracle = [float(np.mean(ref[k]["val_miou"][-4:])) for k in ("oracle_p0", "oracle_p1", "oracle_p2")]
-    batch, ntrain, nval, epochs = 8, 256, 256, 12
-    train = [tuple(t.to(dev) for t in make_batch(i * batch, batch, 64)) for i in range(ntrain // batch)]
-    val = [tuple(t.to(dev) for t in make_batch(i * batch, batch, 64, heldout=True)) for i in range(nval // batch)]
-    net = iu.UNet(2, 2, True, compute_dtype=dtype)
-    net.load_state_dict(cf.fill_state_dict_random(net.state_dict(), seed=7))
-    net = net.to(dev)
-    crit, opt = iu.CrossEntropyLoss(ignore_index=255), iu.Adam(net.parameters(), lr=3e-4)
-    rng = np.random.Generator(np.random.PCG64(4242))
-    curve, vloss = [], []
-    for ep in range(epochs):
-        net.train()
-        for bi in rng.permutation(len(train)):
-            x, y = train[bi]
-            opt.zero_grad()
-            crit(net(x), y).backward()
-            opt.step()
-        net.eval()
-        miou, loss = 0.0, 0.0
-        with torch.no_grad():
-            for x, y in val:
-                lg = net(x)
-                c = confusion_counts(lg, y, 2).cpu().numpy()
-                miou += metrics_from_counts(c[0], c[1], c[2])["miou"] * batch
-                loss += float(crit(lg, y)) * batch
-        curve.append(miou / nval)
-        vloss.append(loss / nval)
-    got = float(np.mean(curve[-4:]))
-    print(f"{dtype}: val mIoU mean(last 4) {got:.4f} (oracle runs {oracle}), val loss {vloss[-1]:.4f}")
-    assert min(oracle) - 0.04 <= got <= max(oracle) + 0.04
-    # single epochs spike in every run (oracle 0.40 / 0.77, HIP 0.78): compare the best validation loss
-    assert min(vloss) <= max(min(ref[k]["val_loss"]) for k in ("oracle_p0", "oracle_p1", "oracle_p2")) + 0.01
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = json.load(open(os.path.join(root, "tests", "golden", "g8c_miou_reference.json")))
+    ref_by_seed = {r["seed"]: r["final"]["val_miou"] for r in ref["runs"]}
+    seeds = sorted(ref_by_seed)[:5]
+    assert len(seeds) >= 5 and ref["config"]["side"] == "reference"
+    out = os.path.join(root, "gpurun_out", f"g8c_miou_hip_{dtype}_test.json")
+    cfg = ref["config"]
+    cmd = [sys.executable, os.path.join(root, "tests", "tools", "miou_experiment.py"), "--side", "hip", "--dtype", dtype,
+           "--seeds", ",".join(str(s) for s in seeds), "--out", out]
+    for k in ("size", "train", "val", "heldout", "batch", "epochs", "lr", "task"):
+        cmd += [f"--{k}", str(cfg[k])]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=900)
+    got = {r["seed"]: r["final"]["val_miou"] for r in json.load(open(out))["runs"]}
+    d = np.array([got[s] - ref_by_seed[s] for s in seeds])
+    t975 = {5: 2.776, 6: 2.571, 7: 2.447, 8: 2.365}[len(seeds)]
+    mean, ci = float(d.mean()), float(t975 * d.std(ddof=1) / np.sqrt(len(d)))
+    r_mean, h_mean = float(np.mean([ref_by_seed[s] for s in seeds])), float(np.mean([got[s] for s in seeds]))
+    print(f"{dtype}: held-out mIoU reference {100 * r_mean:.2f} %, HIP {100 * h_mean:.2f} %; paired difference "
+          f"{100 * mean:+.3f} pt, 95 % CI +-{100 * ci:.3f} pt over seeds {seeds}")
+    assert r_mean >= 0.8                                        # the task is learnt (verdict: mIoU >= 0.8)
+    assert abs(mean) + ci <= 0.003, (mean, ci)                  # the whole interval inside +-0.3 pt
 
 
 def test_boundary_input_forms(dev):
