@@ -771,9 +771,11 @@ def test_unet_bf16_generic_position(dev, golden):
 def test_unet_bf16_error_growth_per_level(dev):
     """What bounds the bf16 error: the same weights and input (the G3r fixture's) through the fp32 and the bf16 HIP plans,
     activation by activation. bf16 keeps fp32 accumulators and fp32 BatchNorm / SE statistics, so the error of a level
-    is the 2^-9 rounding of its stored activations, renormalised by every BatchNorm: it must grow slowly down the
-    encoder, peak at the 4 x 4 bottleneck (32 samples per channel) and come back down the decoder as the skip
-    connections re-inject shallow features. Gates = 2x the values measured on MI355X (printed)."""
+    is the 2^-9 rounding of its stored activations, renormalised by every BatchNorm: it grows by about half a percent to
+    one percent per encoder level and stays flat through the decoder (the skip connections re-inject the shallower,
+    more accurate features). Measured on MI355X (rel-L2): enc0..4 0.0045 / 0.0099 / 0.017 / 0.027 / 0.039, dec3..1
+    0.045 / 0.046 / 0.046, logits 0.049. Gates = 2x those values: a bf16 kernel that drops fp32 accumulation or fp32
+    statistics anywhere shows up as a jump at its level."""
     import insar_unet_ca_amd as iu
     x = cf.make_input_random((2, 2, 64, 64), seed=11).to(dev)
     acts = {}
@@ -781,7 +783,8 @@ def test_unet_bf16_error_growth_per_level(dev):
         net = iu.UNet(2, 2, True, compute_dtype=dt)
         net.load_state_dict(cf.fill_state_dict_random(net.state_dict(), seed=7))
         net = net.to(dev).train()
-        logits = net(x)
+        with torch.no_grad():                   # no lease on the plan: _plan(x) below returns the one that just ran
+            logits = net(x)
         plan = net._plan(x)
         rec = {f"enc{l}": plan.enc[l].out.nchw() for l in range(5)}
         rec.update({f"dec{l}": plan.dec[l].nchw() for l in (3, 2, 1)})
@@ -789,8 +792,8 @@ def test_unet_bf16_error_growth_per_level(dev):
         acts[dt] = rec
     growth = {k: rel_l2(acts[torch.bfloat16][k], acts[torch.float32][k]) for k in acts[torch.float32]}
     print("bf16 vs fp32 rel-L2 per level:", {k: round(v, 4) for k, v in growth.items()})
-    gates = {"enc0": 0.012, "enc1": 0.02, "enc2": 0.03, "enc3": 0.05, "enc4": 0.12, "dec3": 0.12, "dec2": 0.1, "dec1": 0.08,
-             "logits": 0.08}
+    gates = {"enc0": 0.009, "enc1": 0.02, "enc2": 0.035, "enc3": 0.055, "enc4": 0.08, "dec3": 0.09, "dec2": 0.095, "dec1": 0.095,
+             "logits": 0.1}
     for k, gate in gates.items():
         assert growth[k] <= gate, (k, growth[k], gate)
     assert growth["enc0"] < growth["enc4"]
