@@ -496,7 +496,10 @@ class ConvBN:
         self.sums = ctx.f32(self.fold_rows, 2, self.cout) if self.stat_rps else self.stats
         self.scale, self.shift = ctx.f32(self.cout), ctx.f32(self.cout)
         self.mean, self.invstd = ctx.f32(self.cout), ctx.f32(self.cout)
-        self.k1, self.k2 = ctx.f32(self.cout), ctx.f32(self.cout)
+        self.k12 = ctx.f32(2, self.cout)                  # one buffer: SyncBN all-reduces both coefficient vectors at once
+        self.k1, self.k2 = self.k12[0], self.k12[1]
+        self.sync_sums = None                             # [2][C] batch sums of this replica (SyncBN only)
+        self.sync = None
         self.red_rpp = _rows_per_part(B, H)
         self.red_rows = -(-H // self.red_rpp)
         self.red_part = ctx.f32(B * self.red_rows, 2, self.cout)
@@ -505,9 +508,13 @@ class ConvBN:
         self.w = None if self.small else GemmWeight(ctx, conv.weight, "conv3")
 
     # ---- forward: y = conv(x); BN statistics; scale/shift ---------------------------------------
-    def forward_conv(self, training: bool) -> None:
+    def forward_conv(self, training: bool, sync=None) -> None:
+        """sync = (process group, world size): synchronised BatchNorm — the batch statistics are those of the GLOBAL batch
+        (one all-reduce of this layer's [sum, sum of squares] per forward, one of [k1, k2] per backward), which makes
+        data-parallel training equal to the reference's single-device batch ('BatchNorm under DP')."""
         s = _lib.stream_ptr()
-        if training and self.M <= 1:
+        self.sync = sync if training else None
+        if training and self.M <= 1 and not sync:
             # nn.BatchNorm2d's own check (torch.nn.functional._verify_batch_size), same exception and text
             raise ValueError("Expected more than 1 value per channel when training, got input size "
                              f"torch.Size([{self.x.B}, {self.cout}, {self.x.H}, {self.x.W}])")
@@ -533,6 +540,14 @@ class ConvBN:
         bn = self.bn
         d = InsarBnFinalize()
         d.part, d.rows, d.count, d.C, d.training = ptr(self.sums), self.fold_rows, self.M, self.cout, int(training)
+        if self.sync:
+            import torch.distributed as dist
+            pg, world = self.sync
+            if self.sync_sums is None:
+                self.sync_sums = self.ctx.f32(2 * self.cout)
+            self.ctx.colsum(self.sums, self.sync_sums, 1, self.fold_rows, 2 * self.cout)
+            dist.all_reduce(self.sync_sums, op=dist.ReduceOp.SUM, group=pg)
+            d.part, d.rows, d.count = ptr(self.sync_sums), 1, self.M * world
         d.conv_bias = ptr(self.conv.bias.detach()) if self.conv.bias is not None else 0
         d.gamma, d.beta = ptr(bn.weight.detach()), ptr(bn.bias.detach())
         d.running_mean, d.running_var = ptr(bn.running_mean), ptr(bn.running_var)
@@ -554,6 +569,18 @@ class ConvBN:
             return
         call("insar_bn_relu_apply", self.y.ref, ptr(self.scale), ptr(self.shift), ptr(gate), dst.ref, 1,
              _lib.stream_ptr())
+
+    def _sync_k(self) -> None:
+        """SyncBN backward: k1 = mean(g*mask), k2 = mean(g*mask*xhat) over the GLOBAL batch = the mean over the replicas of
+        their local means (equal local batch sizes)."""
+        if getattr(self, "sync", None):
+            import torch.distributed as dist
+            pg, world = self.sync
+            if dist.get_backend(pg) == "nccl":
+                dist.all_reduce(self.k12, op=dist.ReduceOp.AVG, group=pg)
+            else:
+                dist.all_reduce(self.k12, op=dist.ReduceOp.SUM, group=pg)
+                self.k12.div_(world)
 
     # ---- backward -------------------------------------------------------------------------------
     def backward(self, dout: Optional[Act], sink: GradSink, training: bool, se: Optional["SEState"], dx: Optional[Act],
@@ -594,7 +621,7 @@ class ConvBN:
                      dbias, int(training))
         # Training mode: only the per-image stage stays on the dgrad chain; the apply pass folds k1 / k2 from its
         # partial sums itself and the batch fold (parameter gradients) follows the weight gradient on the side stream.
-        split = training and SPLIT_COEF and self.cout <= 1024 and outc_grad is None and pool_grad is None
+        split = training and SPLIT_COEF and self.cout <= 1024 and outc_grad is None and pool_grad is None and not self.sync
         stage2 = None
         if split:
             call("insar_bnse_bwd_coef_stage", *coef_args, 1, s)
@@ -605,16 +632,19 @@ class ConvBN:
             stage2 = lambda: call("insar_bnse_bwd_coef_stage", *coef_args, 2, _lib.stream_ptr())
         elif outc_grad is not None:
             call("insar_bnse_bwd_coef", *coef_args, s)
+            self._sync_k()
             call("insar_bnrelu_bwd_apply_outc", ptr(dl), ptr(wout), K, self.y.ref, ptr(self.scale), ptr(self.shift),
                  ptr(self.mean), ptr(self.invstd), ptr(se.gate) if se else 0, ptr(se.coefB) if se else 0, ptr(self.k1),
                  ptr(self.k2), self.dy.ref, 1, s)
         elif pool_grad is not None:
             call("insar_bnse_bwd_coef", *coef_args, s)
+            self._sync_k()
             call("insar_bnrelu_bwd_apply_pool", dout.ref, dpool.ref, ptr(parg), self.y.ref, ptr(self.scale), ptr(self.shift),
                  ptr(self.mean), ptr(self.invstd), ptr(se.gate) if se else 0, ptr(se.coefB) if se else 0, ptr(self.k1),
                  ptr(self.k2), self.dy.ref, 1, s)
         else:
             call("insar_bnse_bwd_coef", *coef_args, s)
+            self._sync_k()
             call("insar_bnrelu_bwd_apply", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.mean),
                  ptr(self.invstd), ptr(se.gate) if se else 0, ptr(se.coefB) if se else 0, ptr(self.k1), ptr(self.k2),
                  self.dy.ref, 1, s)
@@ -731,13 +761,13 @@ class DoubleConvPlan:
     def params(self) -> List[torch.nn.Parameter]:
         return double_conv_params(self.mod)
 
-    def forward(self, training: bool, outc: Optional["OutConvPlan"] = None) -> Optional[torch.Tensor]:
+    def forward(self, training: bool, outc: Optional["OutConvPlan"] = None, sync=None) -> Optional[torch.Tensor]:
         """outc: the 1x1 output conv when this is the last block and its output goes nowhere else — the final
         BN/ReLU/gate pass then writes the logits instead of `out` (returned)."""
         s = _lib.stream_ptr()
-        self.u1.forward_conv(training)
+        self.u1.forward_conv(training, sync)
         self.u1.apply(self.z1, None)
-        self.u2.forward_conv(training)
+        self.u2.forward_conv(training, sync)
         if self.se:
             se, u2 = self.se, self.u2
             call("insar_se_squeeze", u2.y.ref, ptr(u2.scale), ptr(u2.shift), ptr(se.part), 1, se.rpp, s)
@@ -992,15 +1022,16 @@ class UNetPlan:
         else:
             self.weightset.refresh()
         pack_input(x, self.xin)
+        sync = self.net._hooks.get("sync_bn") if training else None       # (process group, world) under DataParallel(sync_bn=True)
         for l in range(5):
-            self.enc[l].forward(training)          # levels 0-3 write their max-pool too (pool_out)
+            self.enc[l].forward(training, sync=sync)          # levels 0-3 write their max-pool too (pool_out)
         for i in range(3):
             self.up[i].forward()
-            self.dconv[i].forward(training)
+            self.dconv[i].forward(training, sync=sync)
         self.up[3].forward()
         if self.outc.virtual_grad_ok():      # last block: BN/ReLU/gate + outc in one pass, no 64-channel output tensor
-            return self.dconv[3].forward(training, self.outc)
-        self.dconv[3].forward(training)
+            return self.dconv[3].forward(training, self.outc, sync=sync)
+        self.dconv[3].forward(training, sync=sync)
         return self.outc.forward()
 
     # ---- backward ---------------------------------------------------------------------------------

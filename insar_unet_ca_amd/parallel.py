@@ -129,12 +129,13 @@ class DataParallel(torch.nn.Module):
     - every backward pass exchanges the gradients in buckets of >= `bucket_mb` MiB, overlapped with the rest of
       backward: mean all-reduce (default) or, with `shard_optimizer=True`, mean reduce-scatter into this rank's
       shard (use `ShardedAdam` as the optimizer then; `p.grad` stays None);
+    - `sync_bn=True`: BatchNorm statistics over the GLOBAL batch (SyncBN; default: per replica, standard DDP semantics);
     - `forward` and `state_dict` delegate to the wrapped module (no `module.` prefix games:
       use `.module.state_dict()` for reference-compatible checkpoints).
     """
 
     def __init__(self, module: torch.nn.Module, process_group=None, bucket_mb: float = 16.0,
-                 shard_optimizer: bool = False):
+                 shard_optimizer: bool = False, sync_bn: bool = False):
         super().__init__()
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised before wrapping a model in DataParallel")
@@ -158,6 +159,10 @@ class DataParallel(torch.nn.Module):
         module._hooks["on_done"] = self._on_done
         if shard_optimizer:
             module._hooks["grad_mode"] = "none"
+        if sync_bn:
+            # synchronised BatchNorm (U-Net-CA plan): global-batch statistics, i.e. the reference's single-device batch
+            # semantics under data parallelism, for two tiny all-reduces per BatchNorm layer and step
+            module._hooks["sync_bn"] = (process_group, self.world)
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)

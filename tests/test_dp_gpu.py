@@ -114,3 +114,70 @@ def test_data_parallel_over_rccl_single_rank(tmp_path):
     mp.spawn(_nccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
     r = torch.load(tmp_path / "nccl.pt")
     assert r["same"] and r["loss"] == r["loss"]
+
+
+def _syncbn_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd.data import make_batch
+    from insar_unet_ca_amd.parallel import DataParallel
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    net = iu.UNet(2, 2, True).to(dev).train()
+    model = DataParallel(net, bucket_mb=4.0, sync_bn=True)
+    crit = iu.CrossEntropyLoss(ignore_index=255)
+    x, y = make_batch(0, 4, 32)                        # the GLOBAL batch; this rank takes its half
+    xs, ys = x[2 * rank:2 * rank + 2].to(dev), y[2 * rank:2 * rank + 2].to(dev)
+    logits = model(xs)
+    loss = crit(logits, ys)
+    loss.backward()
+    torch.cuda.synchronize()
+    torch.save({"logits": logits.detach().cpu(), "loss": float(loss),
+                "grads": {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()},
+                "rm": net.down4[1].double_conv[4].running_mean.detach().cpu().clone(),
+                "rv": net.inc.double_conv[1].running_var.detach().cpu().clone()}, os.path.join(out_dir, f"sync{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_equals_the_single_device_batch(tmp_path):
+    """DataParallel(sync_bn=True): two replicas of two tiles each reproduce the reference's single-device semantics on the
+    batch of four (Unet-ChannalAttention.py:82,85 computes BatchNorm statistics over the whole batch): same logits, the
+    averaged gradients are the gradients of the full batch, the running statistics are the full batch's. 32 x 32 tiles:
+    the bottleneck sees 2 x 2 x 2 = 8 values per channel per replica, 16 globally."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm device")
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd.data import make_batch
+    port = 29800 + (os.getpid() % 1000)
+    mp.spawn(_syncbn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "sync0.pt"), torch.load(tmp_path / "sync1.pt")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    net = iu.UNet(2, 2, True).to(dev).train()
+    x, y = make_batch(0, 4, 32)
+    logits = net(x.to(dev))
+    loss = iu.CrossEntropyLoss(ignore_index=255)(logits, y.to(dev))
+    loss.backward()
+    full = logits.detach().cpu()
+    scale = float(full.abs().max())
+    assert float((torch.cat([r0["logits"], r1["logits"]]) - full).abs().max()) <= 2e-5 * scale
+    assert abs(0.5 * (r0["loss"] + r1["loss"]) - float(loss)) <= 1e-6
+    assert torch.equal(r0["rm"], r1["rm"])
+    assert float((r0["rm"] - net.down4[1].double_conv[4].running_mean.cpu()).abs().max()) <= 1e-6
+    assert float((r0["rv"] - net.inc.double_conv[1].running_var.cpu()).abs().max()) <= 1e-6
+    worst = 0.0
+    for k, p in net.named_parameters():
+        assert torch.equal(r0["grads"][k], r1["grads"][k]), k              # the exchange left both replicas with the same gradient
+        g = p.grad.cpu()
+        den = float(g.norm())
+        if den < 1e-12:
+            assert float(r0["grads"][k].abs().max()) < 1e-9, k
+            continue
+        worst = max(worst, float((r0["grads"][k] - g).norm()) / den)
+    print(f"SyncBN: worst gradient rel-L2 against the single-device batch {worst:.2e}")
+    assert worst <= 2e-3
