@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("INSAR_HIP_LIB") or os.path.join(_HERE, "libinsar_hip.
 F32, BF16 = 0, 1
 ABI_VERSION = 2
 IGEMM_OOB_ZERO = 1
+IGEMM_PINGPONG = 2
 
 
 class InsarAct(C.Structure):

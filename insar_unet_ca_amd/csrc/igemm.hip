@@ -92,7 +92,13 @@ __device__ __forceinline__ void dma_wait_and_barrier() {
 // OOB: taps may leave the padded input (dilated convolutions, DeepLabV3's ASPP / layer3-4): such (row, tap) pairs
 // are redirected to pixel 0 of the buffer — the top-left halo pixel, all zeros in every channel — by a per-row bounds
 // test on the LDS-DMA source address; rows beyond M read zeros the same way. The U-Net path never needs it.
-template <typename T, int BM, int BN, int NSTAGE, bool OOB = false>
+// PP (256 x 256 tiles, bf16): the K loop as a ping-pong of the two wave groups of the work-group (waves 0-3 / 4-7 = the two
+// waves of every SIMD). A K tile is four phases of 16 MFMAs per wave (one quadrant of its 64-pixel x 128-channel tile, both
+// K halves); each phase = [load part: this quadrant's LDS fragment reads + 2-3 of the 8 LDS-DMA pieces of the NEXT K tile]
+// -> s_barrier -> [compute part: 16 MFMAs] -> s_barrier, and group 1 runs one barrier behind group 0, so that on every
+// SIMD one wave's MFMA cluster runs beside its partner's LDS reads and DMA issue instead of both waves issuing their DMA
+// burst together and then contending for the matrix pipe (the guide's 8-phase schedule, cdna_hip_programming.md §5).
+template <typename T, int BM, int BN, int NSTAGE, bool OOB = false, bool PP = false>
 __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(IgemmArgs a) {
   using Cfg = IgemmCfg<T, BM, BN, NSTAGE>;
   constexpr int ES = Cfg::ES, BKe = Cfg::BKe, CH = Chunk<T>::N;
@@ -146,16 +152,23 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
   constexpr int RPI = THREADS / 8;                  // rows covered by one DMA instruction of the block
   const int srow = tid >> 3;                        // + RPI*i
   const int schunk = ((tid & 7) ^ (srow & 7)) * 16; // swizzled source chunk (bytes)
+  // PP: the LDS image is ordered by (half of the wave's sub-tile, wave, row), so that a phase reads ONE 128-row half of
+  // A or B: LDS row L = h*128 + wm*32 + i holds tile pixel wm*64 + h*32 + i; B row L = c*128 + wn*64 + j holds channel
+  // wn*128 + c*64 + j. The four block-wide DMA instructions of an operand are then its half 0 (two) and half 1 (two).
+  auto a_tile_row = [&](int L) { return PP ? ((L & 127) >> 5) * 64 + (L >> 7) * 32 + (L & 31) : L; };
+  auto b_tile_row = [&](int L) { return PP ? ((L & 127) >> 6) * 128 + (L >> 7) * 64 + (L & 63) : L; };
   const char* a_ptr[Cfg::A_DMA];
   int a_hw[Cfg::A_DMA];
 #pragma unroll
   for (int i = 0; i < Cfg::A_DMA; ++i) {
-    a_ptr[i] = a.x + rowIn[srow + RPI * i] * ES + schunk;
-    a_hw[i] = OOB ? rowHW[srow + RPI * i] : 0;
+    a_ptr[i] = a.x + rowIn[a_tile_row(srow + RPI * i)] * ES + schunk;
+    a_hw[i] = OOB ? rowHW[a_tile_row(srow + RPI * i)] : 0;
   }
   const char* a_zero = a.x + (long long)a.cx_off * ES + schunk;      // pixel 0 = zero halo
-  const long long b_row_bytes = (long long)a.K * ES;
-  const char* b_ptr = a.w + ((long long)(n0 + srow) * a.K) * ES + schunk;
+  const char* b_ptr = a.w + ((long long)(n0 + (PP ? 0 : srow)) * a.K) * ES + schunk;     // PP: per-instruction rows below
+  long long b_row_off[Cfg::B_DMA];
+#pragma unroll
+  for (int i = 0; i < Cfg::B_DMA; ++i) b_row_off[i] = (long long)(PP ? b_tile_row(srow + RPI * i) : RPI * i) * a.K * ES;
   const long long b_tap_bytes = (long long)a.N * a.K * ES;
   const int nk = a.ntaps * a.kc_per_tap;
   const uint32_t lds0 = lds_offset_of(smem);
@@ -182,7 +195,14 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
     const char* wb = b_ptr + tap * b_tap_bytes + (long long)kc * BKe * ES;
     const uint32_t lb = la + Cfg::A_STAGE;
 #pragma unroll
-    for (int i = 0; i < Cfg::B_DMA; ++i) lds_dma16_untracked(wb + (long long)i * RPI * b_row_bytes, lb + i * (THREADS * 16));
+    for (int i = 0; i < Cfg::B_DMA; ++i) lds_dma16_untracked(wb + b_row_off[i], lb + i * (THREADS * 16));
+  };
+  // one DMA piece of a slab (PP schedule): q < A_DMA -> A instruction q, else B instruction q - A_DMA; xoff / wb are the
+  // slab's tap and K-chunk offsets, computed once per K tile
+  auto stage_piece = [&](int buf, long long xoff, const char* wb, int q) {
+    const uint32_t la = lds0 + buf * Cfg::STAGE + wave * 1024;
+    if (q < Cfg::A_DMA) lds_dma16_untracked(a_ptr[q] + xoff, la + q * (THREADS * 16));
+    else lds_dma16_untracked(wb + b_row_off[q - Cfg::A_DMA], la + Cfg::A_STAGE + (q - Cfg::A_DMA) * (THREADS * 16));
   };
 
   f32x4_t acc[NT][MT];
@@ -197,6 +217,75 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
   const int b_frag = (wn * (BN / 2) + r16) * IG_ROWB;      // + nt*16*128
   const int sw = r16 & 7;
 
+  if constexpr (PP) {
+    static_assert(BM == 256 && BN == 256 && NSTAGE == 2 && sizeof(T) == 2 && !OOB, "ping-pong loop: 256 x 256 bf16 tiles");
+    // ---- K loop, ping-pong schedule (see the kernel's header comment) ---------------------------------------
+    // staging order of a K tile's 8 pieces (A0 A0' | B0 B0' B1 | B1' A1 A1'): what phase 1 reads first; phase 4 stages
+    // nothing, so every piece is at least one full phase old when its wait comes
+    const int grp = wave >> 2;                                   // 0: waves 0-3, 1: waves 4-7 (SIMD partners)
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();                   // group 1 runs one barrier behind
+    uint4 xf[2][2], wf[4][2];                                     // [tile][K half]: 2 pixel tiles, 4 channel tiles
+    const int xrow0 = (wm * 32 + r16) * IG_ROWB, wrow0 = (wn * 64 + r16) * IG_ROWB;
+    const int pc0 = ((kq) ^ sw) * 16, pc1 = ((kq + 4) ^ sw) * 16;
+    for (int ks = 0; ks < nk; ++ks) {
+      const int buf = ks & 1;
+      const bool more = ks + 1 < nk;
+      const char* sA = smem + buf * Cfg::STAGE;
+      const char* sB = sA + Cfg::A_STAGE;
+      long long nxoff = 0;
+      const char* nwb = b_ptr;
+      if (more) {
+        const int tap = (ks + 1) / a.kc_per_tap, kc = (ks + 1) - tap * a.kc_per_tap;
+        nxoff = ((long long)stap[tap] + (long long)kc * BKe) * ES;
+        nwb = b_ptr + tap * b_tap_bytes + (long long)kc * BKe * ES;
+      }
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        const int pa = ph >> 1, cb = (ph == 1 || ph == 2) ? 1 : 0;   // quadrants (0,0) (0,1) (1,1) (1,0)
+        // ---- load part ----
+        if (ph == 0 || ph == 2) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const char* p = sA + pa * (128 * IG_ROWB) + xrow0 + m * 16 * IG_ROWB;
+            xf[m][0] = *(const uint4*)(p + pc0); xf[m][1] = *(const uint4*)(p + pc1);
+          }
+        }
+        if (ph != 2) {
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            const char* p = sB + cb * (128 * IG_ROWB) + wrow0 + n * 16 * IG_ROWB;
+            wf[n][0] = *(const uint4*)(p + pc0); wf[n][1] = *(const uint4*)(p + pc1);
+          }
+        }
+        if (more) {
+          if (ph == 0) { stage_piece(buf ^ 1, nxoff, nwb, 0); stage_piece(buf ^ 1, nxoff, nwb, 1); stage_piece(buf ^ 1, nxoff, nwb, 4); }
+          else if (ph == 1) { stage_piece(buf ^ 1, nxoff, nwb, 5); stage_piece(buf ^ 1, nxoff, nwb, 6); stage_piece(buf ^ 1, nxoff, nwb, 7); }
+          else if (ph == 2) { stage_piece(buf ^ 1, nxoff, nwb, 2); stage_piece(buf ^ 1, nxoff, nwb, 3); }
+        }
+        // the slab for the next K tile must have landed before anyone reads it one phase from now; the fragment reads
+        // of this phase must be done before the barrier frees what they read (common.h, dma_drain_and_barrier)
+        if (ph == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- compute part: 16 MFMAs ----
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) Mma<T>::run(wf[n][kh], xf[m][kh], acc[cb * 4 + n][pa * 2 + m]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();                   // group 0 meets group 1's last barrier
+  } else {
   // ---- K loop: NSTAGE-deep LDS ring, NSTAGE-1 slabs in flight ------------------------------------
   constexpr int PER = Cfg::A_DMA + Cfg::B_DMA;    // DMA instructions per wave per slab
 #pragma unroll
@@ -229,6 +318,7 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
     else dma_wait_and_barrier<0>();
     buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
     pbuf = (pbuf + 1 == NSTAGE) ? 0 : pbuf + 1;
+  }
   }
   __syncthreads();
 
@@ -357,18 +447,18 @@ extern "C" int insar_igemm_num_mtiles(int64_t M, int32_t N) {
   return (int)((M + bm - 1) / bm);
 }
 
-template <typename T, int BM, int BN, int NSTAGE, bool OOB = false>
+template <typename T, int BM, int BN, int NSTAGE, bool OOB = false, bool PP = false>
 static int launch_igemm(IgemmArgs& a, hipStream_t s) {
   using Cfg = IgemmCfg<T, BM, BN, NSTAGE>;
   static std::atomic<uint64_t> attr_mask{0};     // per-device, see common.h
   {
-    hipError_t e = insar_set_lds_once(attr_mask, (const void*)igemm_kernel<T, BM, BN, NSTAGE, OOB>, Cfg::LDS_BYTES);
+    hipError_t e = insar_set_lds_once(attr_mask, (const void*)igemm_kernel<T, BM, BN, NSTAGE, OOB, PP>, Cfg::LDS_BYTES);
     if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_igemm: hipFuncSetAttribute(%d bytes LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
   }
   a.num_mtiles = (int)((a.M + BM - 1) / BM);
   a.num_ntiles = a.N / BN;
   const int grid = a.num_mtiles * a.num_ntiles;
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, NSTAGE, OOB>), dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, NSTAGE, OOB, PP>), dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, a);
   INSAR_CHECK_LAUNCH("insar_igemm");
   return INSAR_OK;
 }
@@ -433,7 +523,8 @@ extern "C" int insar_igemm(const InsarIgemm* d, void* stream) {
     return big ? launch_igemm<float, 256, 64, 3, true>(a, s) : launch_igemm<float, 128, 64, 2, true>(a, s);
   }
   if (d->x.dtype == INSAR_BF16) {
-    if (igemm_xwide(a.M, d->N, INSAR_BF16)) return launch_igemm<bf16_t, 256, 256, 2>(a, s);
+    if (igemm_xwide(a.M, d->N, INSAR_BF16))
+      return (d->flags & INSAR_IGEMM_PINGPONG) ? launch_igemm<bf16_t, 256, 256, 2, false, true>(a, s) : launch_igemm<bf16_t, 256, 256, 2>(a, s);
     if (big) return wide ? launch_igemm<bf16_t, 256, 128, 3>(a, s) : launch_igemm<bf16_t, 256, 64, 3>(a, s);
     return wide ? launch_igemm<bf16_t, 128, 128, 2>(a, s) : launch_igemm<bf16_t, 128, 64, 2>(a, s);
   }

@@ -271,6 +271,7 @@ WGRAD_FILL_T = float(os.environ.get("INSAR_WGRAD_FILL_T", "0.5"))   # the same f
 WGRAD_FILL_ALONE = float(os.environ.get("INSAR_WGRAD_FILL_ALONE", "1.0"))   # ... and when it has the GPU to itself
 WGRAD_FILL = float(os.environ.get("INSAR_WGRAD_FILL", "0.5"))     # share of the work-group slots a side-stream weight gradient aims at
 WGRAD_ROWS = os.environ.get("INSAR_WGRAD_ROWS", "1") != "0"      # diagnostic: 0 = per-tap weight-gradient kernel everywhere
+IGEMM_PP = os.environ.get("INSAR_IGEMM_PP", "0") == "1"            # 256 x 256 tiles: ping-pong K loop (A/B switch)
 WGRAD_LATE = os.environ.get("INSAR_WGRAD_ORDER", "before") == "after"      # diagnostic / tuning switch, see ConvBN.backward
 
 
@@ -287,7 +288,7 @@ def _igemm(x: Act, y: Act, w, N: int, Ho: int, Wo: int, stride: int, taps, mode:
     d.x, d.y = x.desc, y.desc
     d.w, d.bias, d.stats = (w if isinstance(w, int) else ptr(w)), ptr(bias), ptr(stats)
     d.N, d.Ho, d.Wo, d.stride, d.ntaps, d.mode = N, Ho, Wo, stride, len(taps), mode
-    d.flags = _lib.IGEMM_OOB_ZERO if oob else 0
+    d.flags = (_lib.IGEMM_OOB_ZERO if oob else 0) | (_lib.IGEMM_PINGPONG if IGEMM_PP else 0)
     d.out_stride, d.out_oy, d.out_ox = out_stride, out_off[0], out_off[1]
     if add is not None:
         if add.C != y.C or add.c_off != y.c_off or add.buf.dtype != y.buf.dtype or add.buf.shape != y.buf.shape:
