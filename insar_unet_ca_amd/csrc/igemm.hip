@@ -92,13 +92,15 @@ __device__ __forceinline__ void dma_wait_and_barrier() {
 // OOB: taps may leave the padded input (dilated convolutions, DeepLabV3's ASPP / layer3-4): such (row, tap) pairs
 // are redirected to pixel 0 of the buffer — the top-left halo pixel, all zeros in every channel — by a per-row bounds
 // test on the LDS-DMA source address; rows beyond M read zeros the same way. The U-Net path never needs it.
-// PP (256 x 256 tiles, bf16): the K loop as a ping-pong of the two wave groups of the work-group (waves 0-3 / 4-7 = the two
-// waves of every SIMD). A K tile is four phases of 16 MFMAs per wave (one quadrant of its 64-pixel x 128-channel tile, both
-// K halves); each phase = [load part: this quadrant's LDS fragment reads + 2-3 of the 8 LDS-DMA pieces of the NEXT K tile]
-// -> s_barrier -> [compute part: 16 MFMAs] -> s_barrier, and group 1 runs one barrier behind group 0, so that on every
-// SIMD one wave's MFMA cluster runs beside its partner's LDS reads and DMA issue instead of both waves issuing their DMA
-// burst together and then contending for the matrix pipe (the guide's 8-phase schedule, cdna_hip_programming.md §5).
-template <typename T, int BM, int BN, int NSTAGE, bool OOB = false, bool PP = false>
+// PP (256-row tiles, bf16): the K loop as a ping-pong of the two wave groups of the work-group (waves 0-3 / 4-7 = the two
+// waves of every SIMD). A K tile is two phases (one half of the wave's 64 pixels each, all of its channels, both K halves);
+// a phase = [load part: the phase's LDS fragment reads + part of the LDS-DMA pieces of the NEXT K tile] -> s_barrier ->
+// [compute part: the phase's MFMAs under s_setprio 1] -> s_barrier, and group 1 runs one barrier behind group 0, so that
+// on every SIMD one wave's MFMA cluster runs beside its partner's LDS reads and DMA issue, instead of both waves issuing
+// their DMA burst together and then contending for the matrix pipe (the role alternation of the guide's 8-phase schedule,
+// cdna_hip_programming.md §5; four phases of 16 MFMAs measured the same as two of 32, so the variant with fewer barriers
+// is kept). Same accumulation order as the plain loop: results are bitwise equal (test_pingpong_k_loop_...).
+template <typename T, int BM, int BN, int NSTAGE, bool OOB = false, int PP = 0>
 __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(IgemmArgs a) {
   using Cfg = IgemmCfg<T, BM, BN, NSTAGE>;
   constexpr int ES = Cfg::ES, BKe = Cfg::BKe, CH = Chunk<T>::N;
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
   // A or B: LDS row L = h*128 + wm*32 + i holds tile pixel wm*64 + h*32 + i; B row L = c*128 + wn*64 + j holds channel
   // wn*128 + c*64 + j. The four block-wide DMA instructions of an operand are then its half 0 (two) and half 1 (two).
   auto a_tile_row = [&](int L) { return PP ? ((L & 127) >> 5) * 64 + (L >> 7) * 32 + (L & 31) : L; };
-  auto b_tile_row = [&](int L) { return PP ? ((L & 127) >> 6) * 128 + (L >> 7) * 64 + (L & 63) : L; };
+  auto b_tile_row = [&](int L) { return L; };       // B is read whole in the first phase of a K tile: natural row order
   const char* a_ptr[Cfg::A_DMA];
   int a_hw[Cfg::A_DMA];
 #pragma unroll
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
   const int sw = r16 & 7;
 
   if constexpr (PP) {
-    static_assert(BM == 256 && BN == 256 && NSTAGE == 2 && sizeof(T) == 2 && !OOB, "ping-pong loop: 256 x 256 bf16 tiles");
+    static_assert(BM == 256 && NSTAGE == 2 && sizeof(T) == 2 && !OOB, "ping-pong loop: 256-row bf16 tiles, two LDS slabs");
     // ---- K loop, ping-pong schedule (see the kernel's header comment) ---------------------------------------
     // staging order of a K tile's 8 pieces (A0 A0' | B0 B0' B1 | B1' A1 A1'): what phase 1 reads first; phase 4 stages
     // nothing, so every piece is at least one full phase old when its wait comes
@@ -227,8 +229,13 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();                   // group 1 runs one barrier behind
-    uint4 xf[2][2], wf[4][2];                                     // [tile][K half]: 2 pixel tiles, 4 channel tiles
-    const int xrow0 = (wm * 32 + r16) * IG_ROWB, wrow0 = (wn * 64 + r16) * IG_ROWB;
+    {
+    // two phases per K tile: pixel half 0, then pixel half 1 of the wave's 64 pixels, each against all of the wave's BN/2
+    // channels (2 * NT MFMAs per phase and K half). Phase A reads x0 + every w fragment and stages A0 A0' + all of B of
+    // the next tile; phase B reads x1 and stages A1 A1'. Waits: phase B retires the pieces of phase A (a phase old, its own
+    // two stay in flight); phase A retires the two A1 pieces issued at the end of the tile before (read in phase B).
+    uint4 xf[2][2], wf[NT][2];
+    const int xrow0 = (wm * 32 + r16) * IG_ROWB;
     const int pc0 = ((kq) ^ sw) * 16, pc1 = ((kq + 4) ^ sw) * 16;
     for (int ks = 0; ks < nk; ++ks) {
       const int buf = ks & 1;
@@ -243,46 +250,43 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
         nwb = b_ptr + tap * b_tap_bytes + (long long)kc * BKe * ES;
       }
 #pragma unroll
-      for (int ph = 0; ph < 4; ++ph) {
-        const int pa = ph >> 1, cb = (ph == 1 || ph == 2) ? 1 : 0;   // quadrants (0,0) (0,1) (1,1) (1,0)
-        // ---- load part ----
-        if (ph == 0 || ph == 2) {
+      for (int pa = 0; pa < 2; ++pa) {
 #pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            const char* p = sA + pa * (128 * IG_ROWB) + xrow0 + m * 16 * IG_ROWB;
-            xf[m][0] = *(const uint4*)(p + pc0); xf[m][1] = *(const uint4*)(p + pc1);
-          }
+        for (int m = 0; m < 2; ++m) {
+          const char* p = sA + pa * (128 * IG_ROWB) + xrow0 + m * 16 * IG_ROWB;
+          xf[m][0] = *(const uint4*)(p + pc0); xf[m][1] = *(const uint4*)(p + pc1);
         }
-        if (ph != 2) {
+        if (pa == 0) {
 #pragma unroll
-          for (int n = 0; n < 4; ++n) {
-            const char* p = sB + cb * (128 * IG_ROWB) + wrow0 + n * 16 * IG_ROWB;
+          for (int n = 0; n < NT; ++n) {
+            const char* p = sB + b_frag + n * 16 * IG_ROWB;
             wf[n][0] = *(const uint4*)(p + pc0); wf[n][1] = *(const uint4*)(p + pc1);
           }
         }
         if (more) {
-          if (ph == 0) { stage_piece(buf ^ 1, nxoff, nwb, 0); stage_piece(buf ^ 1, nxoff, nwb, 1); stage_piece(buf ^ 1, nxoff, nwb, 4); }
-          else if (ph == 1) { stage_piece(buf ^ 1, nxoff, nwb, 5); stage_piece(buf ^ 1, nxoff, nwb, 6); stage_piece(buf ^ 1, nxoff, nwb, 7); }
-          else if (ph == 2) { stage_piece(buf ^ 1, nxoff, nwb, 2); stage_piece(buf ^ 1, nxoff, nwb, 3); }
+          if (pa == 0) {
+            stage_piece(buf ^ 1, nxoff, nwb, 0); stage_piece(buf ^ 1, nxoff, nwb, 1);
+#pragma unroll
+            for (int i = 0; i < Cfg::B_DMA; ++i) stage_piece(buf ^ 1, nxoff, nwb, Cfg::A_DMA + i);
+          } else { stage_piece(buf ^ 1, nxoff, nwb, 2); stage_piece(buf ^ 1, nxoff, nwb, 3); }
         }
-        // the slab for the next K tile must have landed before anyone reads it one phase from now; the fragment reads
-        // of this phase must be done before the barrier frees what they read (common.h, dma_drain_and_barrier)
-        if (ph == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (pa == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 + Cfg::B_DMA) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        // ---- compute part: 16 MFMAs ----
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-          for (int n = 0; n < 4; ++n)
+          for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) Mma<T>::run(wf[n][kh], xf[m][kh], acc[cb * 4 + n][pa * 2 + m]);
+            for (int m = 0; m < 2; ++m) Mma<T>::run(wf[n][kh], xf[m][kh], acc[n][pa * 2 + m]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
       }
+    }
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();                   // group 0 meets group 1's last barrier
   } else {
@@ -447,7 +451,7 @@ extern "C" int insar_igemm_num_mtiles(int64_t M, int32_t N) {
   return (int)((M + bm - 1) / bm);
 }
 
-template <typename T, int BM, int BN, int NSTAGE, bool OOB = false, bool PP = false>
+template <typename T, int BM, int BN, int NSTAGE, bool OOB = false, int PP = 0>
 static int launch_igemm(IgemmArgs& a, hipStream_t s) {
   using Cfg = IgemmCfg<T, BM, BN, NSTAGE>;
   static std::atomic<uint64_t> attr_mask{0};     // per-device, see common.h
@@ -524,7 +528,8 @@ extern "C" int insar_igemm(const InsarIgemm* d, void* stream) {
   }
   if (d->x.dtype == INSAR_BF16) {
     if (igemm_xwide(a.M, d->N, INSAR_BF16))
-      return (d->flags & INSAR_IGEMM_PINGPONG) ? launch_igemm<bf16_t, 256, 256, 2, false, true>(a, s) : launch_igemm<bf16_t, 256, 256, 2>(a, s);
+      return (d->flags & INSAR_IGEMM_PINGPONG) ? launch_igemm<bf16_t, 256, 256, 2, false, 2>(a, s) : launch_igemm<bf16_t, 256, 256, 2>(a, s);
+    if (big && wide && (d->flags & INSAR_IGEMM_PINGPONG)) return launch_igemm<bf16_t, 256, 128, 2, false, 2>(a, s);
     if (big) return wide ? launch_igemm<bf16_t, 256, 128, 3>(a, s) : launch_igemm<bf16_t, 256, 64, 3>(a, s);
     return wide ? launch_igemm<bf16_t, 128, 128, 2>(a, s) : launch_igemm<bf16_t, 128, 64, 2>(a, s);
   }

@@ -70,6 +70,38 @@ def _halo_abs(a):
 # ------------------------------------------------------------------------------------------------
 # kernel level: implicit GEMM forward / dgrad / wgrad, transposed conv — tight, no ReLU involved
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cin,cout,shape", [(64, 512, (2, 64, 128, 128)), (256, 64, (4, 256, 128, 128)), (256, 256, (16, 256, 64, 64)),
+                                            (512, 512, (16, 512, 32, 32)), (128, 128, (8, 128, 100, 128))])   # the last two: 256 x 128 tiles
+def test_pingpong_k_loop_is_bitwise_the_plain_loop(dev, cin, cout, shape, monkeypatch):
+    """The 256 x 256-tile kernel's ping-pong K loop (INSAR_IGEMM_PINGPONG) accumulates every output in the same order as the
+    plain two-slab loop: forward (with BatchNorm partial sums) and input gradient must agree bit for bit, many times over
+    (its LDS hand-off between the two wave groups is the kind of code whose races come and go)."""
+    from insar_unet_ca_amd import engine
+    from insar_unet_ca_amd._lib import call
+    dtype = torch.bfloat16
+    ctx = engine.Ctx(dev, dtype)
+    b, _, h, w = shape
+    xa = _act_from(cf.make_input_random(shape, seed=3), dtype, dev)
+    ga = _act_from(cf.make_input_random((b, cout, h, w), seed=4), dtype, dev)
+    p = torch.nn.Parameter(cf.fill_tensor("weight", (cout, cin, 3, 3), 11).to(dev))
+    gw = engine.GemmWeight(ctx, p, "conv3")
+    rows = call("insar_igemm_num_mtiles", b * h * w, cout)
+    assert call("insar_igemm_tile_rows", b * h * w, cout) == 256 and call("insar_igemm_tile_cols_dt", b * h * w, cout, 1) >= 128
+    outs = {}
+    for pp in (0, 1):
+        monkeypatch.setattr(engine, "IGEMM_PP", pp)
+        ya = engine.Act.alloc(b, h, w, cout, dtype, dev)
+        dxa = engine.Act.alloc(b, h, w, cin, dtype, dev)
+        stats = torch.zeros(rows, 2, cout, device=dev)
+        for _ in range(25 if pp else 1):
+            engine._igemm(xa, ya, gw.fwd(), cout, h, w, 1, engine._TAPS3, 0, stats=stats)
+            engine._igemm(ga, dxa, gw.dgrad(), cin, h, w, 1, engine._TAPS3_DGRAD, 0)
+            if pp:
+                assert torch.equal(ya.buf, outs[0][0]) and torch.equal(dxa.buf, outs[0][1]) and torch.equal(stats, outs[0][2])
+        outs[pp] = (ya.buf.clone(), dxa.buf.clone(), stats.clone())
+    assert float(outs[1][0].float().abs().max()) > 0
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cin,cout,shape", [
     (64, 128, (2, 64, 16, 16)),

@@ -50,16 +50,16 @@ def main():
             return e0.elapsed_time(e1) / a.iters * 1e3
         res = []
         if "pp" in what:       # same-process A/B of the ping-pong K loop (256 x 256 tiles only): interleaved rounds
-            rounds = {False: [], True: []}
+            rounds = {0: [], 1: []}
             for r in range(4):
-                for pp in (False, True):
+                for pp in (0, 1):
                     engine.IGEMM_PP = pp
                     rounds[pp].append((run(lambda: engine._igemm(x, y, wf, cout, hw, hw, 1, engine._TAPS3, 0, stats=stats)),
                                        run(lambda: engine._igemm(g, dx, wd, cin, hw, hw, 1, engine._TAPS3_DGRAD, 0))))
-            engine.IGEMM_PP = False
-            for pp in (False, True):
+            engine.IGEMM_PP = 0
+            for pp in (0, 1):
                 f = sorted(v[0] for v in rounds[pp]); d = sorted(v[1] for v in rounds[pp])
-                res.append(f"{'pingpong' if pp else 'plain'}: fwd min {f[0]:6.1f} med {f[len(f)//2]:6.1f} us ({flops/f[0]/1e6:6.0f} TF) dgrad min {d[0]:6.1f} med {d[len(d)//2]:6.1f} us ({flops/d[0]/1e6:6.0f} TF)")
+                res.append(f"pp{pp}: fwd min {f[0]:6.1f} med {f[len(f)//2]:6.1f} us ({flops/f[0]/1e6:6.0f} TF) dgrad min {d[0]:6.1f} med {d[len(d)//2]:6.1f} us ({flops/d[0]/1e6:6.0f} TF)")
         if "fwd" in what:
             us = run(lambda: engine._igemm(x, y, wf, cout, hw, hw, 1, engine._TAPS3, 0, stats=stats)); res.append(f"fwd {us:7.1f} us {flops/us/1e6:7.1f} TF")
         if "dgrad" in what:
