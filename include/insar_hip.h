@@ -105,8 +105,7 @@ typedef struct InsarIgemm {
 /* flags. OOB_ZERO: taps may leave the padded input and read zeros there (dilated 3x3 convolutions of DeepLabV3's
  * layer3 / layer4 / ASPP, torchvision resnet.py / deeplabv3.py; the 1-pixel halo covers only |dy|,|dx| <= 1). */
 enum { INSAR_IGEMM_OOB_ZERO = 1,
-       INSAR_IGEMM_PINGPONG = 2 /* bf16 tiles of 256 rows x 256 / 128 channels: the ping-pong K loop (csrc/igemm.hip); same
-                                 * results, bit for bit */ };
+       INSAR_IGEMM_PINGPONG = 2 /* 256 x 256 bf16 tiles: the ping-pong K loop (csrc/igemm.hip); same results, bit for bit */ };
 /* rows of the stats slab = number of M tiles the library will use for a GEMM with M rows and N columns
  * (the tile height, 128 or 256 pixels, is chosen from M and N so that the grid fills the 256 CUs). */
 int insar_igemm_num_mtiles(int64_t M, int32_t N);

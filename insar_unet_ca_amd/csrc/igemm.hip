@@ -529,7 +529,8 @@ extern "C" int insar_igemm(const InsarIgemm* d, void* stream) {
   if (d->x.dtype == INSAR_BF16) {
     if (igemm_xwide(a.M, d->N, INSAR_BF16))
       return (d->flags & INSAR_IGEMM_PINGPONG) ? launch_igemm<bf16_t, 256, 256, 2, false, 2>(a, s) : launch_igemm<bf16_t, 256, 256, 2>(a, s);
-    if (big && wide && (d->flags & INSAR_IGEMM_PINGPONG)) return launch_igemm<bf16_t, 256, 128, 2, false, 2>(a, s);
+    // (the ping-pong loop on 256 x 128 tiles was measured too: 512 -> 512 at 32 x 32 75.1 -> 75.5 us, 1024 -> 512 forward
+    //  140.8 -> 147.6 us: with half the MFMAs per LDS-DMA piece the load part of a phase outlasts its partner's compute part)
     if (big) return wide ? launch_igemm<bf16_t, 256, 128, 3>(a, s) : launch_igemm<bf16_t, 256, 64, 3>(a, s);
     return wide ? launch_igemm<bf16_t, 128, 128, 2>(a, s) : launch_igemm<bf16_t, 128, 64, 2>(a, s);
   }

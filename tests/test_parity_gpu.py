@@ -71,7 +71,7 @@ def _halo_abs(a):
 # kernel level: implicit GEMM forward / dgrad / wgrad, transposed conv — tight, no ReLU involved
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cin,cout,shape", [(64, 512, (2, 64, 128, 128)), (256, 64, (4, 256, 128, 128)), (256, 256, (16, 256, 64, 64)),
-                                            (512, 512, (16, 512, 32, 32)), (128, 128, (8, 128, 100, 128))])   # the last two: 256 x 128 tiles
+                                            (1024, 256, (16, 1024, 32, 32))])
 def test_pingpong_k_loop_is_bitwise_the_plain_loop(dev, cin, cout, shape, monkeypatch):
     """The 256 x 256-tile kernel's ping-pong K loop (INSAR_IGEMM_PINGPONG) accumulates every output in the same order as the
     plain two-slab loop: forward (with BatchNorm partial sums) and input gradient must agree bit for bit, many times over
@@ -86,7 +86,7 @@ def test_pingpong_k_loop_is_bitwise_the_plain_loop(dev, cin, cout, shape, monkey
     p = torch.nn.Parameter(cf.fill_tensor("weight", (cout, cin, 3, 3), 11).to(dev))
     gw = engine.GemmWeight(ctx, p, "conv3")
     rows = call("insar_igemm_num_mtiles", b * h * w, cout)
-    assert call("insar_igemm_tile_rows", b * h * w, cout) == 256 and call("insar_igemm_tile_cols_dt", b * h * w, cout, 1) >= 128
+    assert 256 in (call("insar_igemm_tile_cols_dt", b * h * w, cout, 1), call("insar_igemm_tile_cols_dt", b * h * w, cin, 1))
     outs = {}
     for pp in (0, 1):
         monkeypatch.setattr(engine, "IGEMM_PP", pp)
