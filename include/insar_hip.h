@@ -170,8 +170,7 @@ int insar_wgrad(const InsarWgrad* d, void* stream);
  * (tile(Cin) << 16) | tile(Cout) (tiles <= 128), or 0 when the layer needs insar_wgrad (W neither a multiple of 64
  * nor 16 / 32). */
 int insar_wgrad_conv3_tile(const InsarAct* x, int32_t Cout);
-enum { INSAR_WGRAD3_PINGPONG = 1 /* 128 x 128 bf16 tiles (8 waves): ping-pong K loop, bitwise the plain loop's slabs */ };
-int insar_wgrad_conv3(const InsarAct* x, const InsarAct* dy, float* part, int32_t nsplit, int32_t flags, void* stream);
+int insar_wgrad_conv3(const InsarAct* x, const InsarAct* dy, float* part, int32_t nsplit, void* stream);
 /* grad = sum_split part[...] re-laid out to the torch parameter layout.
  * layout 0: Conv2d (Co,Ci,kh,kw): grad[(co*Ci+ci)*ntaps + tap]
  * layout 1: ConvTranspose2d (Ci,Co,2,2): grad[(ci*Co+co)*ntaps + tap]

@@ -103,7 +103,7 @@ _SIGNATURES = {
     "insar_wgrad_tile": [_I, _I],
     "insar_wgrad_tile_pair": [_I, _I, _I],
     "insar_wgrad_conv3_tile": [_AP, _I],
-    "insar_wgrad_conv3": [_AP, _AP, _P, _I, _I, _P],
+    "insar_wgrad_conv3": [_AP, _AP, _P, _I, _P],
     "insar_wgrad_reduce": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "insar_wgrad_fold": [_P, _P, _L, _I, _I, _P],
     "insar_pixel_table": [_P, _L, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -54,11 +54,7 @@ struct Wgrad3Cfg {
   static_assert(YCHUNKS % THREADS == 0, "dY stage must be whole block-wide DMA instructions");
 };
 
-// PP (8 waves, bf16): the K loop as a ping-pong of the two wave groups (waves 0-3 / 4-7, the two waves of every SIMD), as
-// in igemm.hip: a K step is two phases (its two 32-pixel halves); a phase = [load part: the half's dY and X fragments for
-// the three taps; in the first phase also the LDS-DMA pieces of the NEXT K step] -> s_barrier -> [its 3*MTW*NTW MFMAs] ->
-// s_barrier, with group 1 one barrier behind group 0. Same accumulation order: bitwise the plain loop's slabs.
-template <typename T, int TM, int TN, int NW, bool PP = false>
+template <typename T, int TM, int TN, int NW>
 __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad3_kernel(Wgrad3Args a) {
   using Cfg = Wgrad3Cfg<T, TM, TN, NW>;
   constexpr int THREADS = Cfg::THREADS, ES = Cfg::ES;
@@ -147,75 +143,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad3_kernel(Wgra
   const int wm = wave & 1, wn = wave >> 1;
   const int r16 = lane & 15, kq = lane >> 4;
 
-  if constexpr (PP) {
-    static_assert(NW == 8 && sizeof(T) == 2, "ping-pong loop: the 8-wave bf16 kernel");
-    if (ks0 < ks1) {
-      const int grp = wave >> 2;
-      stage(0, next_pixel());
-      dma_drain_and_barrier();
-      if (grp == 1) __builtin_amdgcn_s_barrier();               // group 1 runs one barrier behind
-      for (int ks = ks0; ks < ks1; ++ks) {
-        const int buf = (ks - ks0) & 1;
-        const bool more = ks + 1 < ks1;
-        const long long pnext = more ? next_pixel() : 0;
-        const char* sX = smem + buf * Cfg::STAGE;
-        const char* sY = sX + Cfg::X_STAGE;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          // ---- load part ----
-          bf16x8_t yf[NTW], xf[3][MTW];
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int sel = h ^ (kq & 1);
-            const int k = s * 32 + kq * 8 + sel * 4 + (r16 >> 2);
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-              const int colw = (wn * (NTW * 16) + nt * 16 + (r16 & 3) * 4) * 2;
-              int sub = 0, colb = colw;
-              if constexpr (Cfg::SUBY > 1) { sub = colw / Cfg::RBY; colb = colw % Cfg::RBY; }
-              const int pc = (colb >> 4) ^ w3_swz<Cfg::RBY>(k);
-              const char* p = sY + sub * (W3_BKP * Cfg::RBY) + k * Cfg::RBY + pc * 16 + (colb & 15);
-              s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
-              yf[nt][4 * h + 0] = v[0]; yf[nt][4 * h + 1] = v[1]; yf[nt][4 * h + 2] = v[2]; yf[nt][4 * h + 3] = v[3];
-            }
-#pragma unroll
-            for (int t3 = 0; t3 < 3; ++t3) {
-              const int row = k + 2 * (k >> a.lw) + t3;
-#pragma unroll
-              for (int mt = 0; mt < MTW; ++mt) {
-                const int colw = (wm * (TM / 2) + mt * 16 + (r16 & 3) * 4) * 2;
-                int sub = 0, colb = colw;
-                if constexpr (Cfg::SUBX > 1) { sub = colw / Cfg::RBX; colb = colw % Cfg::RBX; }
-                const int pc = (colb >> 4) ^ w3_swz<Cfg::RBX>(row);
-                const char* p = sX + sub * (W3_XR * Cfg::RBX) + row * Cfg::RBX + pc * 16 + (colb & 15);
-                s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
-                xf[t3][mt][4 * h + 0] = v[0]; xf[t3][mt][4 * h + 1] = v[1]; xf[t3][mt][4 * h + 2] = v[2]; xf[t3][mt][4 * h + 3] = v[3];
-              }
-            }
-          }
-          if (s == 0 && more) stage(buf ^ 1, pnext);
-          // the next K step's pieces (issued one phase ago) must have landed before anyone reads them one phase from now;
-          // this phase's fragment reads must be complete before the barrier that lets the other group restage them
-          if (s == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-          else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-          __builtin_amdgcn_sched_barrier(0);
-          __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-          for (int t3 = 0; t3 < 3; ++t3)
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-              for (int nt = 0; nt < NTW; ++nt)
-                acc[t3][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[t3][mt], yf[nt], acc[t3][mt][nt], 0, 0, 0);
-          __builtin_amdgcn_s_setprio(0);
-          __builtin_amdgcn_sched_barrier(0);
-          __builtin_amdgcn_s_barrier();
-        }
-      }
-      if (grp == 0) __builtin_amdgcn_s_barrier();               // group 0 meets group 1's last barrier
-    }
-  } else
   if (ks0 < ks1) {
     stage(0, next_pixel());
     dma_drain_and_barrier();
@@ -320,18 +247,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad3_kernel(Wgra
   }
 }
 
-template <typename T, int TM, int TN, int NW, bool PP = false>
+template <typename T, int TM, int TN, int NW>
 static int launch_wgrad3(Wgrad3Args& a, hipStream_t s) {
   using Cfg = Wgrad3Cfg<T, TM, TN, NW>;
   static std::atomic<uint64_t> attr_mask{0};     // per-device, see common.h
   {
-    hipError_t e = insar_set_lds_once(attr_mask, (const void*)wgrad3_kernel<T, TM, TN, NW, PP>, Cfg::LDS_BYTES);
+    hipError_t e = insar_set_lds_once(attr_mask, (const void*)wgrad3_kernel<T, TM, TN, NW>, Cfg::LDS_BYTES);
     if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_wgrad_conv3: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   a.mtc = a.Cin / TM; a.ntc = a.Cout / TN;
   const long long grid = (long long)a.nsplit * 3 * a.mtc * a.ntc;
   if (grid > 0x7fffffffLL) INSAR_FAIL(INSAR_E_SHAPE, "insar_wgrad_conv3: grid too large");
-  hipLaunchKernelGGL((wgrad3_kernel<T, TM, TN, NW, PP>), dim3((unsigned)grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((wgrad3_kernel<T, TM, TN, NW>), dim3((unsigned)grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, a);
   INSAR_CHECK_LAUNCH("insar_wgrad_conv3");
   return INSAR_OK;
 }
@@ -354,7 +281,7 @@ extern "C" int insar_wgrad_conv3_tile(const InsarAct* x, int32_t Cout) {
 
 // part[split][tap][co][ci] (tap = 3*ty + tx, the layout insar_wgrad writes) for a 3x3 / stride-1 / pad-1 convolution:
 // x (B, H, W, Cin) and dy (B, H, W, Cout) on the same grid; nsplit splits of the B*H*W/64 K steps.
-extern "C" int insar_wgrad_conv3(const InsarAct* x, const InsarAct* dy, float* part, int32_t nsplit, int32_t flags, void* stream) {
+extern "C" int insar_wgrad_conv3(const InsarAct* x, const InsarAct* dy, float* part, int32_t nsplit, void* stream) {
   if (!x || !dy || !part) INSAR_FAIL(INSAR_E_ARG, "insar_wgrad_conv3: null pointer");
   int rc;
   if ((rc = insar_check_act(x, "insar_wgrad_conv3", "x"))) return rc;
@@ -381,8 +308,7 @@ extern "C" int insar_wgrad_conv3(const InsarAct* x, const InsarAct* dy, float* p
     if (tm == 128 && tn == 128) return launch_wgrad3<float, 128, 128, 8>(a, s);
     return launch_wgrad3<float, 64, 64, 4>(a, s);
   }
-  if (tm == 128 && tn == 128)
-    return (flags & INSAR_WGRAD3_PINGPONG) ? launch_wgrad3<bf16_t, 128, 128, 8, true>(a, s) : launch_wgrad3<bf16_t, 128, 128, 8>(a, s);
+  if (tm == 128 && tn == 128) return launch_wgrad3<bf16_t, 128, 128, 8>(a, s);
   if (tm == 128) return launch_wgrad3<bf16_t, 128, 64, 4>(a, s);
   if (tn == 128) return launch_wgrad3<bf16_t, 64, 128, 4>(a, s);
   return launch_wgrad3<bf16_t, 64, 64, 4>(a, s);

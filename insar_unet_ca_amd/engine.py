@@ -271,7 +271,6 @@ WGRAD_FILL_T = float(os.environ.get("INSAR_WGRAD_FILL_T", "0.5"))   # the same f
 WGRAD_FILL_ALONE = float(os.environ.get("INSAR_WGRAD_FILL_ALONE", "1.0"))   # ... and when it has the GPU to itself
 WGRAD_FILL = float(os.environ.get("INSAR_WGRAD_FILL", "0.5"))     # share of the work-group slots a side-stream weight gradient aims at
 WGRAD_ROWS = os.environ.get("INSAR_WGRAD_ROWS", "1") != "0"      # diagnostic: 0 = per-tap weight-gradient kernel everywhere
-WGRAD3_PP = int(os.environ.get("INSAR_WGRAD3_PP", "0"))           # 128 x 128 row-of-taps weight gradient: ping-pong K loop
 IGEMM_PP = int(os.environ.get("INSAR_IGEMM_PP", "1"))            # 256 x 256 tiles: ping-pong K loop (0 = the plain two-slab loop; bitwise equal)
 WGRAD_LATE = os.environ.get("INSAR_WGRAD_ORDER", "before") == "after"      # diagnostic / tuning switch, see ConvBN.backward
 
@@ -707,9 +706,9 @@ def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
             # algorithmic bytes: both operands read once, the split-K slabs written once
             nbytes = ctx.esize * B * H * W * (cin + cout) + 4.0 * nsplit * 9 * cout * cin
             PROFILER.run(tag, 2.0 * B * H * W * cin * cout * 9,
-                         lambda: call("insar_wgrad_conv3", x.ref, dy.ref, ptr(part), nsplit, int(WGRAD3_PP), _lib.stream_ptr()), nbytes)
+                         lambda: call("insar_wgrad_conv3", x.ref, dy.ref, ptr(part), nsplit, _lib.stream_ptr()), nbytes)
         else:
-            call("insar_wgrad_conv3", x.ref, dy.ref, ptr(part), nsplit, int(WGRAD3_PP), _lib.stream_ptr())
+            call("insar_wgrad_conv3", x.ref, dy.ref, ptr(part), nsplit, _lib.stream_ptr())
         ctx.wgrad_finish(part, grad, nsplit, 9, cout, cin, 0)
         return
     tabx = ctx.pixel_table(B, H, W, 1, H, W, W + 3)      # taps move on x: tail = first interior pixel

@@ -60,21 +60,6 @@ def main():
             for pp in (0, 1):
                 f = sorted(v[0] for v in rounds[pp]); d = sorted(v[1] for v in rounds[pp])
                 res.append(f"pp{pp}: fwd min {f[0]:6.1f} med {f[len(f)//2]:6.1f} us ({flops/f[0]/1e6:6.0f} TF) dgrad min {d[0]:6.1f} med {d[len(d)//2]:6.1f} us ({flops/d[0]/1e6:6.0f} TF)")
-        if "wpp" in what:      # same-process A/B of the row-of-taps weight gradient's ping-pong loop (128 x 128 tiles)
-            rounds = {0: [], 1: []}
-            for r in range(4):
-                for pp in (0, 1):
-                    engine.WGRAD3_PP = pp
-                    rounds[pp].append(run(lambda: engine._wgrad_conv3(ctx, x, g, grad)))
-            ref = None
-            for pp in (0, 1):
-                engine.WGRAD3_PP = pp
-                grad.zero_(); engine._wgrad_conv3(ctx, x, g, grad); torch.cuda.synchronize()
-                if ref is None: ref = grad.clone()
-                same = torch.equal(ref, grad)
-                v = sorted(rounds[pp])
-                res.append(f"wgrad pp{pp}: min {v[0]:6.1f} med {v[len(v)//2]:6.1f} us ({flops/v[0]/1e6:6.0f} TF incl. folds) bitwise={same}")
-            engine.WGRAD3_PP = 0
         if "fwd" in what:
             us = run(lambda: engine._igemm(x, y, wf, cout, hw, hw, 1, engine._TAPS3, 0, stats=stats)); res.append(f"fwd {us:7.1f} us {flops/us/1e6:7.1f} TF")
         if "dgrad" in what:
