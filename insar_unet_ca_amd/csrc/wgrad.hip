@@ -360,10 +360,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
   for (int idx = threadIdx.x; idx < ntaps * nci; idx += blockDim.x) {
     const int tap = idx / nci, c = idx - tap * nci;
     const float* p = part + (long long)tap * total + (long long)co * Ci + ci0 + c;
-    float s = 0.f;
-#pragma unroll 4
-    for (int sp = 0; sp < nsplit; ++sp) s += p[(long long)sp * slab];
-    t[c * ntaps + tap] = s;
+    // four interleaved partial sums (fixed order: deterministic), so that four slab reads are in flight per thread
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int sp = 0;
+    for (; sp + 4 <= nsplit; sp += 4) {
+      s0 += p[(long long)sp * slab]; s1 += p[(long long)(sp + 1) * slab];
+      s2 += p[(long long)(sp + 2) * slab]; s3 += p[(long long)(sp + 3) * slab];
+    }
+    for (; sp < nsplit; ++sp) s0 += p[(long long)sp * slab];
+    t[c * ntaps + tap] = (s0 + s1) + (s2 + s3);
   }
   __syncthreads();
   if (layout == 0) {

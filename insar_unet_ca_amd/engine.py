@@ -119,7 +119,7 @@ class Ctx:
         """Fold the split-K slabs (two stages when there are many) and write the torch-layout gradient."""
         s = _lib.stream_ptr()
         slab = ntaps * cout * cin
-        if nsplit > 12:
+        if nsplit > 48:           # up to 48 slabs the re-layout kernel folds them itself (four reads in flight per thread)
             group = 8 if nsplit <= 96 else 16
             groups = (nsplit + group - 1) // group
             if self._wgrad_fold is None or self._wgrad_fold.numel() < groups * slab:
