@@ -1,32 +1,47 @@
 #!/bin/bash
 # Round-end measurement pass on the GPU box: GPU tests, race screens, the bench line, rocprofv3 kernel stats (two-stream
-# and single-stream) and the two PMC passes behind roofline.traffic. Results under gpurun_out/$1 (default: final).
+# and single-stream), the two PMC passes behind roofline.traffic, a kernel-trace timeline of steady-state steps, and the
+# other configurations (config 4, config 5, hipGraph replay). Results under gpurun_out/$1 (default: final).
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/${1:-final}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-echo "== pytest"; timeout -k 10 500 python3 -m pytest "$R/tests" -m gpu -x -q -p no:cacheprovider > "$OUT/pytest_gpu.log" 2>&1; tail -n 2 "$OUT/pytest_gpu.log"
+echo "== pytest"; timeout -k 10 900 python3 -m pytest "$R/tests" -m gpu -q -p no:cacheprovider > "$OUT/pytest_gpu.log" 2>&1; tail -n 2 "$OUT/pytest_gpu.log"
 echo "== race screens"
 RUNS=40 STEPS=24 timeout -k 10 200 python3 "$R/tools/debug_race_steps.py" 2>/dev/null | tee "$OUT/race_steps.log" || exit 1
 RUNS=600 timeout -k 10 300 python3 "$R/tools/debug_race.py" 2>/dev/null | tail -n 1 | tee "$OUT/race_step.log" || exit 1
 echo "== bench"; timeout -k 10 400 python3 "$R/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err" || exit 1
 cut -c1-330 "$OUT/bench.json"
 echo "== phase times"; timeout -k 10 100 python3 "$R/tools/phase_times.py" 2>/dev/null | tee "$OUT/phase_times.log"
-echo "== rocprof stats (default: two streams + event pass)"
+echo "== rocprof stats (default command: timed region on two streams + the two event passes)"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/p1" -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/p1.log" 2>&1 || exit 1
+echo "== rocprof stats (timed region only, two streams)"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/p3" -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing > "$OUT/p3.log" 2>&1 || exit 1
 echo "== rocprof stats (single stream)"
 INSAR_SIDE_STREAM=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/p2" -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing > "$OUT/p2.log" 2>&1 || exit 1
-echo "== PMC passes (single stream: the launch configuration of the per-kernel event pass behind roofline.achieved)"
+echo "== PMC passes (single stream: every kernel alone on the chip)"
 INSAR_SIDE_STREAM=0 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pF" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing > "$OUT/pF.log" 2>&1 || exit 1
 INSAR_SIDE_STREAM=0 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pW" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing > "$OUT/pW.log" 2>&1 || exit 1
+echo "== kernel trace (timeline of 4 steady-state steps)"
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/pT" -- python3 "$R/bench.py" --steps 4 --warmup 3 --no-cpu-baseline --no-kernel-timing > "$OUT/pT.log" 2>&1 || exit 1
 cp $(ls "$OUT"/p1/*/*_kernel_stats.csv | head -n 1) "$OUT/bench_kernel_stats.csv"
+cp $(ls "$OUT"/p3/*/*_kernel_stats.csv | head -n 1) "$OUT/bench_kernel_stats_timed_region.csv"
 cp $(ls "$OUT"/p2/*/*_kernel_stats.csv | head -n 1) "$OUT/bench_kernel_stats_single_stream.csv"
 cp $(ls "$OUT"/pF/*/*_counter_collection.csv | head -n 1) "$OUT/pmc_fetch.csv"
 cp $(ls "$OUT"/pW/*/*_counter_collection.csv | head -n 1) "$OUT/pmc_write.csv"
+cp $(ls "$OUT"/pT/*/*_kernel_trace.csv | head -n 1) "$OUT/kernel_trace.csv"
 python3 "$R/tools/pmc_traffic.py" "$OUT/pmc_fetch.csv" "$OUT/pmc_write.csv" "$OUT/pmc_traffic.json"
-rm -rf "$OUT/p1" "$OUT/p2" "$OUT/pF" "$OUT/pW"      # keep the summaries only (the traces are large)
+python3 "$R/tools/timeline.py" "$OUT/kernel_trace.csv" | tee "$OUT/timeline.txt"
+rm -rf "$OUT/p1" "$OUT/p2" "$OUT/p3" "$OUT/pF" "$OUT/pW" "$OUT/pT" "$OUT/pmc_fetch.csv" "$OUT/pmc_write.csv"      # keep the summaries only
+echo "== hipGraph replay vs eager launches"
+timeout -k 10 300 python3 "$R/bench.py" --graph on --no-cpu-baseline --no-kernel-timing --steps 30 --warmup 5 > "$OUT/bench_graph.json" 2> "$OUT/bench_graph.err"; cut -c1-200 "$OUT/bench_graph.json"
+timeout -k 10 300 python3 "$R/bench.py" --graph off --no-cpu-baseline --no-kernel-timing --steps 30 --warmup 5 > "$OUT/bench_eager.json" 2> "$OUT/bench_eager.err"; cut -c1-200 "$OUT/bench_eager.json"
+echo "== microbench: ping-pong K loop, same-process A/B"
+timeout -k 10 300 python3 "$R/tools/gemm_bench.py" --only down2.3,conv2.0,conv1.0 --what pp 2>/dev/null | tee "$OUT/gemm_pingpong_ab.txt"
 echo "== 2-rank rehearsal (gloo, both ranks on the one GPU: exercises the bucketed reducer inside backward)"
 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 "$R/bench.py" --gpus 2 --steps 3 --warmup 1 --backend gloo --no-cpu-baseline --no-kernel-timing > "$OUT/bench_dp2_gloo.json" 2> "$OUT/bench_dp2_gloo.err"; cut -c1-160 "$OUT/bench_dp2_gloo.json"
+timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 "$R/bench.py" --gpus 2 --steps 3 --warmup 1 --backend gloo --shard-optimizer --no-cpu-baseline --no-kernel-timing > "$OUT/bench_dp2_gloo_sharded.json" 2> "$OUT/bench_dp2_gloo_sharded.err"; cut -c1-160 "$OUT/bench_dp2_gloo_sharded.json"
 echo "== config 4"; timeout -k 10 300 python3 "$R/bench.py" --dtype f32 --size 512 --batch 8 --loss ce --no-cpu-baseline > "$OUT/bench_cfg4.json" 2> "$OUT/bench_cfg4.err"; cut -c1-200 "$OUT/bench_cfg4.json"
+echo "== config 5"; timeout -k 10 300 python3 "$R/bench.py" --model deeplab --no-cpu-baseline > "$OUT/bench_cfg5.json" 2> "$OUT/bench_cfg5.err"; cut -c1-200 "$OUT/bench_cfg5.json"
 echo done
