@@ -252,8 +252,9 @@ def main() -> int:
         out["roofline_step"] = {"bound": bound, "achieved": round(fl if bound == "mfma" else bw, 2),
                                 "peak": peak if bound == "mfma" else PEAK_HBM_GBS, "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
                                 "frac": round(max(fl / peak, bw / PEAK_HBM_GBS), 4),
-                                "algorithmic": f"{flop_tile / 1e9:.1f} GFLOP and {bytes_tile / 1e6:.0f} MB per tile "
-                                               "(SURVEY 8d), whole step incl. loss and Adam, timed region"}
+                                "algorithmic": (f"{flop_tile / 1e9:.1f} GFLOP and {bytes_tile / 1e6:.0f} MB per tile (SURVEY 8d)" if act_bytes is not None
+                                                else f"{flop_tile / 1e9:.1f} GFLOP per tile (layer shapes of the plan; no byte model)")
+                                               + ", whole step incl. loss and Adam, timed region"}
         if act_bytes is None:
             out.pop("frac_of_hbm_roofline")
         if timers:
