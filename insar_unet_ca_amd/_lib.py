@@ -211,8 +211,16 @@ def call(name: str, *args) -> int:
     return 0
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_get_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr() -> int:
-    """The caller's HIP stream (torch's current stream): kernels are enqueued there, never synced."""
+    """The caller's HIP stream (torch's current stream on the current device): kernels are enqueued there, never synced.
+    (torch.cuda.current_stream() builds a Stream object and resolves the device three times: 8 us per call, 0.6-2 ms of
+    host time per training step; the raw accessors return the same handle in 0.3 us.)"""
+    if _raw_stream is not None and _get_device is not None:
+        return _raw_stream(_get_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -232,7 +232,7 @@ class ConvUnit:
         d = InsarBnFinalize()
         d.part, d.rows, d.count, d.C, d.training = ptr(self.sums), self.fold_rows, self.M, self.cout, int(training)
         d.conv_bias = 0
-        d.gamma, d.beta = ptr(bn.weight.detach()), ptr(bn.bias.detach())
+        d.gamma, d.beta = ptr(bn.weight), ptr(bn.bias)
         d.running_mean, d.running_var = ptr(bn.running_mean), ptr(bn.running_var)
         d.num_batches_tracked = ptr(bn.num_batches_tracked)
         d.momentum = bn.momentum if bn.momentum is not None else 0.1
@@ -505,7 +505,7 @@ class DeepLabPlan:
         z = self.head.out
         d.B, d.H, d.W, d.C, d.Cr, d.rows = z.B, z.H, z.W, 256, self.cam_cr, self.cam_rows
         d.psum, d.pmax, d.parg = ptr(self.cam_psum), ptr(self.cam_pmax), ptr(self.cam_parg)
-        d.w1, d.w2 = ptr(self.cam_mod.mlp[0].weight.detach()), ptr(self.cam_mod.mlp[2].weight.detach())
+        d.w1, d.w2 = ptr(self.cam_mod.mlp[0].weight), ptr(self.cam_mod.mlp[2].weight)
         d.avg, d.mx, d.arg = ptr(self.cam_avg), ptr(self.cam_mx), ptr(self.cam_arg)
         d.ha, d.hm, d.gate = ptr(self.cam_ha), ptr(self.cam_hm), ptr(self.cam_gate)
         d.coefB, d.dmax, d.ws = ptr(self.cam_coefB), ptr(self.cam_dmax), ptr(self.cam_ws)
@@ -525,7 +525,7 @@ class DeepLabPlan:
         # stem (:144 backbone): conv7x7 s2 -> BN -> ReLU -> MaxPool(3, 2, 1)
         if training and self.B * (self.H // 2) * (self.W // 2) <= 1:
             raise ValueError("Expected more than 1 value per channel when training")
-        call("insar_conv7x7s2_fwd", ptr(self.x_in), self.H, self.W, ptr(self.stem_conv.weight.detach()), self.y0.ref,
+        call("insar_conv7x7s2_fwd", ptr(self.x_in), self.H, self.W, ptr(self.stem_conv.weight), self.y0.ref,
              ptr(self.st_stats) if training else 0, s)
         if training and self.st_rps:
             call("insar_colsum_partial", ptr(self.st_stats), ptr(self.st_sums), self.st_rows, 128, self.st_rps, s)
@@ -533,7 +533,7 @@ class DeepLabPlan:
         d = InsarBnFinalize()
         d.part, d.rows, d.count, d.C, d.training = ptr(self.st_sums), self.st_fold, self.B * (self.H // 2) * (self.W // 2), 64, int(training)
         d.conv_bias = 0
-        d.gamma, d.beta = ptr(bn.weight.detach()), ptr(bn.bias.detach())
+        d.gamma, d.beta = ptr(bn.weight), ptr(bn.bias)
         d.running_mean, d.running_var, d.num_batches_tracked = ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked)
         d.momentum, d.eps = (bn.momentum if bn.momentum is not None else 0.1), bn.eps
         d.scale, d.shift, d.mean, d.invstd = ptr(self.st_scale), ptr(self.st_shift), ptr(self.st_mean), ptr(self.st_invstd)

@@ -549,8 +549,8 @@ class ConvBN:
             self.ctx.colsum(self.sums, self.sync_sums, 1, self.fold_rows, 2 * self.cout)
             dist.all_reduce(self.sync_sums, op=dist.ReduceOp.SUM, group=pg)
             d.part, d.rows, d.count = ptr(self.sync_sums), 1, self.M * world
-        d.conv_bias = ptr(self.conv.bias.detach()) if self.conv.bias is not None else 0
-        d.gamma, d.beta = ptr(bn.weight.detach()), ptr(bn.bias.detach())
+        d.conv_bias = ptr(self.conv.bias) if self.conv.bias is not None else 0
+        d.gamma, d.beta = ptr(bn.weight), ptr(bn.bias)
         d.running_mean, d.running_var = ptr(bn.running_mean), ptr(bn.running_var)
         d.num_batches_tracked = ptr(bn.num_batches_tracked)
         d.momentum = bn.momentum if bn.momentum is not None else 0.1
@@ -611,7 +611,7 @@ class ConvBN:
         d.mean, d.invstd = ptr(self.mean), ptr(self.invstd)
         if se:
             d.pooled, d.sq, d.hid, d.gate = ptr(se.pooled), ptr(se.sq), ptr(se.hid), ptr(se.gate)
-            d.w1, d.w2 = ptr(se.fc1.weight.detach()), ptr(se.fc2.weight.detach())
+            d.w1, d.w2 = ptr(se.fc1.weight), ptr(se.fc2.weight)
             d.dw1, d.dw2 = ptr(sink.view(se.fc1.weight)), ptr(sink.view(se.fc2.weight))
             d.coefB = ptr(se.coefB)
         d.dgamma, d.dbeta = ptr(sink.view(self.bn.weight)), ptr(sink.view(self.bn.bias))
@@ -776,7 +776,7 @@ class DoubleConvPlan:
             d.part, d.rows, d.pooled = ptr(se.part), se.rows, ptr(se.pooled)
             d.B, d.H, d.W, d.C, d.Cr = self.x.B, self.x.H, self.x.W, u2.cout, se.cr
             d.scale, d.shift = ptr(u2.scale), ptr(u2.shift)
-            d.w1, d.w2 = ptr(se.fc1.weight.detach()), ptr(se.fc2.weight.detach())
+            d.w1, d.w2 = ptr(se.fc1.weight), ptr(se.fc2.weight)
             d.sq, d.hid, d.gate = ptr(se.sq), ptr(se.hid), ptr(se.gate)
             call("insar_se_excite", C.byref(d), s)
             if outc is not None:
@@ -874,8 +874,8 @@ class OutConvPlan:
         self.fused_src = None
         x = self.x
         logits = torch.empty((x.B, self.K, x.H, x.W), dtype=torch.float32, device=self.ctx.device)
-        call("insar_conv1x1_out_fwd", x.ref, ptr(self.mod.weight.detach()),
-             ptr(self.mod.bias.detach()) if self.mod.bias is not None else 0, ptr(logits), self.K, _lib.stream_ptr())
+        call("insar_conv1x1_out_fwd", x.ref, ptr(self.mod.weight),
+             ptr(self.mod.bias) if self.mod.bias is not None else 0, ptr(logits), self.K, _lib.stream_ptr())
         return logits
 
     def forward_fused(self, unit: "ConvBN", gate: Optional[torch.Tensor]) -> torch.Tensor:
@@ -883,8 +883,8 @@ class OutConvPlan:
         unit's output activation is never written)."""
         y = unit.y
         logits = torch.empty((y.B, self.K, y.H, y.W), dtype=torch.float32, device=self.ctx.device)
-        call("insar_bn_relu_apply_outc", y.ref, ptr(unit.scale), ptr(unit.shift), ptr(gate), ptr(self.mod.weight.detach()),
-             ptr(self.mod.bias.detach()) if self.mod.bias is not None else 0, ptr(logits), self.K, 1, _lib.stream_ptr())
+        call("insar_bn_relu_apply_outc", y.ref, ptr(unit.scale), ptr(unit.shift), ptr(gate), ptr(self.mod.weight),
+             ptr(self.mod.bias) if self.mod.bias is not None else 0, ptr(logits), self.K, 1, _lib.stream_ptr())
         self.fused_src = (unit, gate)
         return logits
 
@@ -908,13 +908,13 @@ class OutConvPlan:
                 if self.fused_src is not None:       # the input activation was never stored: recompute it from y
                     unit, gate = self.fused_src
                     call("insar_conv1x1_out_wgrad_y", unit.y.ref, ptr(unit.scale), ptr(unit.shift), ptr(gate),
-                         ptr(self.mod.weight.detach()), ptr(dlogits), self.K, ptr(self.part), _lib.stream_ptr())
+                         ptr(self.mod.weight), ptr(dlogits), self.K, ptr(self.part), _lib.stream_ptr())
                 else:
-                    call("insar_conv1x1_out_wgrad", self.x.ref, ptr(self.mod.weight.detach()), ptr(dlogits), self.K,
+                    call("insar_conv1x1_out_wgrad", self.x.ref, ptr(self.mod.weight), ptr(dlogits), self.K,
                          ptr(self.part), _lib.stream_ptr())
                 fold()
             return
-        call("insar_conv1x1_out_bwd", self.x.ref, ptr(self.mod.weight.detach()), ptr(dlogits), self.K, dx.ref,
+        call("insar_conv1x1_out_bwd", self.x.ref, ptr(self.mod.weight), ptr(dlogits), self.K, dx.ref,
              ptr(self.part), _lib.stream_ptr())
         with self.ctx.side_stream():            # folds are off the critical path
             fold()

@@ -125,7 +125,7 @@ class _SEPlan:
         d.part, d.rows, d.pooled = ptr(self.part), self.rows, ptr(self.pooled)
         d.B, d.H, d.W, d.C, d.Cr = self.B, self.H, self.W, self.C, self.cr
         d.scale, d.shift = ptr(self.ones), ptr(self.zeros)
-        d.w1, d.w2 = ptr(self.mod.fc[0].weight.detach()), ptr(self.mod.fc[2].weight.detach())
+        d.w1, d.w2 = ptr(self.mod.fc[0].weight), ptr(self.mod.fc[2].weight)
         d.sq, d.hid, d.gate = ptr(self.sq), ptr(self.hid), ptr(self.gate)
         call("insar_se_excite", C.byref(d), s)
         call("insar_bn_relu_apply", self.x.ref, ptr(self.ones), ptr(self.zeros), ptr(self.gate), self.out.ref, 0, s)
@@ -141,7 +141,7 @@ class _SEPlan:
         d.mean, d.invstd = ptr(self.zeros), ptr(self.ones)
         d.pooled, d.sq, d.hid, d.gate = ptr(self.pooled), ptr(self.sq), ptr(self.hid), ptr(self.gate)
         w1, w2 = self.mod.fc[0].weight, self.mod.fc[2].weight
-        d.w1, d.w2 = ptr(w1.detach()), ptr(w2.detach())
+        d.w1, d.w2 = ptr(w1), ptr(w2)
         d.dw1, d.dw2 = ptr(self.sink.view(w1)), ptr(self.sink.view(w2))
         d.dgamma, d.dbeta = ptr(self.scratch[0]), ptr(self.scratch[1])
         d.coefB, d.k1, d.k2 = ptr(self.coefB), ptr(self.k1), ptr(self.k2)
@@ -225,7 +225,7 @@ class _CamPlan:
         d = InsarCam()
         d.B, d.H, d.W, d.C, d.Cr, d.rows = self.B, self.H, self.W, self.C, self.cr, self.rows
         d.psum, d.pmax, d.parg = ptr(self.psum), ptr(self.pmax), ptr(self.parg)
-        d.w1, d.w2 = ptr(self.mod.mlp[0].weight.detach()), ptr(self.mod.mlp[2].weight.detach())   # (Cr,C,1,1), (C,Cr,1,1)
+        d.w1, d.w2 = ptr(self.mod.mlp[0].weight), ptr(self.mod.mlp[2].weight)   # (Cr,C,1,1), (C,Cr,1,1)
         d.avg, d.mx, d.arg = ptr(self.avg), ptr(self.mx), ptr(self.arg)
         d.ha, d.hm, d.gate = ptr(self.ha), ptr(self.hm), ptr(self.gate)
         d.coefB, d.dmax, d.ws = ptr(self.coefB), ptr(self.dmax), ptr(self.ws)
