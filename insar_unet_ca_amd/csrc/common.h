@@ -97,9 +97,15 @@ int insar_check_act(const InsarAct* a, const char* who, const char* what);
 // (nondeterministic BatchNorm partial sums in ~1 % of the work-groups). Pattern used wherever a batch of
 // freshly reduced values goes to LDS: materialise the values (LDS_PIN), store, drain (LDS_DRAIN), and keep
 // the source registers alive across the drain (LDS_KEEP) so the allocator cannot recycle them early.
+#ifdef INSAR_NO_LDS_GUARD      // diagnostic build (tools/lds_guard_experiment.sh): the guard compiled out
+#define LDS_PIN(x)
+#define LDS_KEEP(x)
+#define LDS_DRAIN()
+#else
 #define LDS_PIN(x) asm volatile("" : "+v"(x))
 #define LDS_KEEP(x) asm volatile("" ::"v"(x))
 #define LDS_DRAIN() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
 
 // ---- LDS-DMA issued behind the compiler's back ------------------------------------------------
 // hipcc (ROCm 7.2) makes every ds_read that follows a __builtin_amdgcn_global_load_lds wait vmcnt(0)
