@@ -91,20 +91,22 @@ static inline ActView make_view(const InsarAct& a) {
 // Validate an activation slice: aligned base, 16-byte-aligned channel slice.
 int insar_check_act(const InsarAct* a, const char* who, const char* what);
 
-// ---- LDS store hazard guard -----------------------------------------------------------------
-// Observed on gfx950 (hipcc 7.2): a wide LDS store (ds_write_b128) whose data registers are overwritten
-// by VALU instructions a few slots later occasionally delivers a stale dword when the LDS pipe is busy
-// (nondeterministic BatchNorm partial sums in ~1 % of the work-groups). Pattern used wherever a batch of
-// freshly reduced values goes to LDS: materialise the values (LDS_PIN), store, drain (LDS_DRAIN), and keep
-// the source registers alive across the drain (LDS_KEEP) so the allocator cannot recycle them early.
-#ifdef INSAR_NO_LDS_GUARD      // diagnostic build (tools/lds_guard_experiment.sh): the guard compiled out
-#define LDS_PIN(x)
-#define LDS_KEEP(x)
-#define LDS_DRAIN()
-#else
+// ---- LDS store guard (retired) ----------------------------------------------------------------
+// Round 1 saw nondeterministic BatchNorm partial sums in ~1 % of the work-groups and attributed them to a wide LDS store
+// (ds_write_b128) whose data registers are overwritten by VALU instructions a few slots later; the "guard" materialised
+// the values (LDS_PIN), stored, drained (LDS_DRAIN) and kept the source registers alive across the drain (LDS_KEEP). The
+// real cause turned out to be the WAR race at the K-step barrier (dma_drain_and_barrier below): with that fixed,
+// a build WITHOUT the guard gives one result over 80 repeats of a 24-step training run (tools/lds_guard_experiment.sh,
+// round 2), the same as the guarded build. The macros are therefore no-ops; -DINSAR_LDS_GUARD brings the guard back for
+// an A/B should the symptom ever return.
+#ifdef INSAR_LDS_GUARD
 #define LDS_PIN(x) asm volatile("" : "+v"(x))
 #define LDS_KEEP(x) asm volatile("" ::"v"(x))
 #define LDS_DRAIN() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define LDS_PIN(x)
+#define LDS_KEEP(x)
+#define LDS_DRAIN()
 #endif
 
 // ---- LDS-DMA issued behind the compiler's back ------------------------------------------------
