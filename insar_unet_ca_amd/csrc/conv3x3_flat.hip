@@ -70,7 +70,11 @@ __device__ __forceinline__ void fl_wait_and_barrier() {
   __builtin_amdgcn_s_barrier();
 }
 
-template <typename T, int BN>
+// PP (bf16): every tap step as one ping-pong phase of the two wave groups (waves 0-3 / 4-7, the two waves of every SIMD), as
+// in igemm.hip: [load part: the step's fragment reads + the LDS-DMA pieces the plain loop issues in this step] -> s_barrier
+// -> [its 2*NT*MT MFMAs under s_setprio 1] -> s_barrier, group 1 one barrier behind group 0. A staged slab is waited for
+// one phase after it was issued and read one phase after that wait. Same accumulation order as the plain loop.
+template <typename T, int BN, bool PP = false>
 __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a) {
   using Cfg = FlatCfg<T, BN>;
   constexpr int ES = Cfg::ES, BKe = Cfg::BKe, CH = Chunk<T>::N;
@@ -152,6 +156,68 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
   const int kcs = a.kc_count;
   const int nsteps = kcs * 9, ngroups = kcs * 3;
 
+  if constexpr (PP) {
+    static_assert(sizeof(T) == 2, "ping-pong loop: bf16");
+    const int grp = wave >> 2;
+    stageA(0, 0, 0);
+    stageB(0, 0, 0);
+    stageB(1, 0, 1);
+    fl_wait_and_barrier<0>();           // everything landed; rowOut visible
+    if (grp == 1) __builtin_amdgcn_s_barrier();                 // group 1 runs one barrier behind
+    for (int kc = 0; kc < kcs; ++kc) {
+#pragma unroll
+      for (int dyi = 0; dyi < 3; ++dyi) {
+        const int g = kc * 3 + dyi;
+        const char* sA = smem + (g & 1) * Cfg::A_SLOT;
+#pragma unroll
+        for (int dxi = 0; dxi < 3; ++dxi) {
+          const int s = g * 3 + dxi;
+          const bool issueA = (dxi == 0) && (g + 1 < ngroups);
+          const bool issueB = (s + 2 < nsteps);
+          const char* sB = smem + 2 * Cfg::A_SLOT + dxi * Cfg::B_SLOT;
+          // ---- load part ----
+          uint4 xf[2][MT], wf[2][NT];
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              int row = arow0 + mt * 16 + (dxi - 1);
+              row = row < 0 ? 0 : (row > FL_BM - 1 ? FL_BM - 1 : row);
+              xf[sub][mt] = *(const uint4*)(sA + row * FL_ROWB + (((kq + 4 * sub) ^ (row & 7)) << 4));
+            }
+            const int pcb = ((kq + 4 * sub) ^ swb) << 4;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[sub][nt] = *(const uint4*)(sB + b_frag + nt * 16 * FL_ROWB + pcb);
+          }
+          if (issueA) stageA((g + 1) & 1, dyi == 2 ? kc + 1 : kc, dyi == 2 ? 0 : dyi + 1);
+          if (issueB) {
+            const int dx2 = (dxi + 2) % 3;
+            const int gg = g + (dxi + 2) / 3;
+            const int kc2 = gg / 3, dy2 = gg - kc2 * 3;
+            stageB(dx2, kc2, dy2 * 3 + dx2);
+          }
+          // everything issued BEFORE this phase has landed (it is at least a phase old); this phase's reads are complete
+          if (issueA && issueB) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(AD + BD) : "memory");
+          else if (issueA) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(AD) : "memory");
+          else if (issueB) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BD) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) FMma<T>::run(wf[sub][nt], xf[sub][mt], acc[nt][mt]);
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_barrier();
+        }
+      }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();                 // group 0 meets group 1's last barrier
+  } else {
   // prologue: A(group 0), B(step 0), B(step 1)
   stageA(0, 0, 0);
   stageB(0, 0, 0);
@@ -208,6 +274,7 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
         }
       }
     }
+  }
   }
   __syncthreads();
 
@@ -299,17 +366,17 @@ extern "C" int insar_conv3x3_flat_ok(const InsarAct* x, int32_t N) {
 }
 extern "C" int insar_conv3x3_flat_num_mtiles(const InsarAct* x) { return x ? flat_mtiles(flat_pixels(*x)) : 0; }
 
-template <typename T, int BN>
+template <typename T, int BN, bool PP = false>
 static int launch_flat(FlatArgs& a, hipStream_t s) {
   using Cfg = FlatCfg<T, BN>;
   static std::atomic<uint64_t> attr_mask{0};     // per-device, see common.h
   {
-    hipError_t e = insar_set_lds_once(attr_mask, (const void*)conv3x3_flat_kernel<T, BN>, Cfg::LDS_BYTES);
+    hipError_t e = insar_set_lds_once(attr_mask, (const void*)conv3x3_flat_kernel<T, BN, PP>, Cfg::LDS_BYTES);
     if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_conv3x3_flat: hipFuncSetAttribute(%d bytes LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
   }
   a.num_ntiles = a.N / BN;
   const long long grid = (long long)a.num_mtiles * a.num_ntiles;
-  hipLaunchKernelGGL((conv3x3_flat_kernel<T, BN>), dim3((unsigned)grid), dim3(FL_THREADS), Cfg::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((conv3x3_flat_kernel<T, BN, PP>), dim3((unsigned)grid), dim3(FL_THREADS), Cfg::LDS_BYTES, s, a);
   INSAR_CHECK_LAUNCH("insar_conv3x3_flat");
   return INSAR_OK;
 }
@@ -337,10 +404,12 @@ extern "C" int insar_conv3x3_flat(const InsarAct* x, const InsarAct* y, const vo
   a.P = P; a.B = x->B; a.H = x->H; a.W = x->W;
   a.Cx = x->C; a.cx_off = x->c_off; a.K = x->c_len;
   a.Cy = y->C; a.cy_off = y->c_off; a.N = y->c_len;
-  a.kc_count = x->c_len / bke; a.flip = flip ? 1 : 0;
+  a.kc_count = x->c_len / bke; a.flip = (flip & 1) ? 1 : 0;
+  const bool pp = (flip & 2) != 0;
   a.num_mtiles = flat_mtiles(P);
   hipStream_t s = (hipStream_t)stream;
   const bool wide = (a.N % 128) == 0;
+  if (x->dtype == INSAR_BF16 && pp) return wide ? launch_flat<bf16_t, 128, true>(a, s) : launch_flat<bf16_t, 64, true>(a, s);
   if (x->dtype == INSAR_BF16) return wide ? launch_flat<bf16_t, 128>(a, s) : launch_flat<bf16_t, 64>(a, s);
   return wide ? launch_flat<float, 128>(a, s) : launch_flat<float, 64>(a, s);
 }

@@ -271,6 +271,7 @@ WGRAD_FILL_T = float(os.environ.get("INSAR_WGRAD_FILL_T", "0.5"))   # the same f
 WGRAD_FILL_ALONE = float(os.environ.get("INSAR_WGRAD_FILL_ALONE", "1.0"))   # ... and when it has the GPU to itself
 WGRAD_FILL = float(os.environ.get("INSAR_WGRAD_FILL", "0.5"))     # share of the work-group slots a side-stream weight gradient aims at
 WGRAD_ROWS = os.environ.get("INSAR_WGRAD_ROWS", "1") != "0"      # diagnostic: 0 = per-tap weight-gradient kernel everywhere
+FLAT_PP = int(os.environ.get("INSAR_FLAT_PP", "0"))               # flat 3x3 kernel: ping-pong tap steps (A/B switch)
 IGEMM_PP = int(os.environ.get("INSAR_IGEMM_PP", "1"))            # 256 x 256 tiles: ping-pong K loop (0 = the plain two-slab loop; bitwise equal)
 WGRAD_LATE = os.environ.get("INSAR_WGRAD_ORDER", "before") == "after"      # diagnostic / tuning switch, see ConvBN.backward
 
@@ -315,9 +316,9 @@ def _conv3x3_flat(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[to
     if PROFILER is not None:
         flops = 2.0 * x.B * x.H * x.W * y.c_len * x.c_len * 9
         tag = "conv3x3_flat_kernel<%s, %d>" % ("float" if x.code == _lib.F32 else "bf16_t", 128 if y.c_len % 128 == 0 else 64)
-        PROFILER.run(tag, flops, lambda: call("insar_conv3x3_flat", x.ref, y.ref, ptr(w), flip, ptr(stats), _lib.stream_ptr()))
+        PROFILER.run(tag, flops, lambda: call("insar_conv3x3_flat", x.ref, y.ref, ptr(w), flip | (2 if FLAT_PP else 0), ptr(stats), _lib.stream_ptr()))
         return
-    call("insar_conv3x3_flat", x.ref, y.ref, ptr(w), flip, ptr(stats), _lib.stream_ptr())
+    call("insar_conv3x3_flat", x.ref, y.ref, ptr(w), flip | (2 if FLAT_PP else 0), ptr(stats), _lib.stream_ptr())
 
 
 def _conv3x3_c64(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[torch.Tensor]) -> None:

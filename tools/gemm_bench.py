@@ -64,6 +64,24 @@ def main():
             us = run(lambda: engine._igemm(x, y, wf, cout, hw, hw, 1, engine._TAPS3, 0, stats=stats)); res.append(f"fwd {us:7.1f} us {flops/us/1e6:7.1f} TF")
         if "dgrad" in what:
             us = run(lambda: engine._igemm(g, dx, wd, cin, hw, hw, 1, engine._TAPS3_DGRAD, 0)); res.append(f"dgrad {us:7.1f} us {flops/us/1e6:7.1f} TF")
+        if "fpp" in what:      # same-process A/B of the flat kernel's ping-pong tap steps
+            from insar_unet_ca_amd._lib import ptr
+            rows = call("insar_conv3x3_flat_num_mtiles", x.ref)
+            st2 = torch.zeros(rows, 2, cout, device=dev)
+            rounds = {0: [], 2: []}
+            for r in range(4):
+                for pp in (0, 2):
+                    rounds[pp].append((run(lambda: call("insar_conv3x3_flat", x.ref, y.ref, ptr(wf), 0 | pp, ptr(st2), _lib.stream_ptr())),
+                                       run(lambda: call("insar_conv3x3_flat", g.ref, dx.ref, ptr(wd), 1 | pp, 0, _lib.stream_ptr()))))
+            outs = {}
+            for pp in (0, 2):
+                y.buf.zero_(); dx.buf.zero_(); st2.zero_()
+                call("insar_conv3x3_flat", x.ref, y.ref, ptr(wf), 0 | pp, ptr(st2), _lib.stream_ptr())
+                call("insar_conv3x3_flat", g.ref, dx.ref, ptr(wd), 1 | pp, 0, _lib.stream_ptr()); torch.cuda.synchronize()
+                outs[pp] = (y.buf.clone(), dx.buf.clone(), st2.clone())
+                f = sorted(v[0] for v in rounds[pp]); d = sorted(v[1] for v in rounds[pp])
+                res.append(f"flat pp{pp}: fwd min {f[0]:6.1f} med {f[len(f)//2]:6.1f} us ({flops/f[0]/1e6:6.0f} TF) dgrad min {d[0]:6.1f} med {d[len(d)//2]:6.1f} us ({flops/d[0]/1e6:6.0f} TF)")
+            res.append("bitwise=" + str(all(torch.equal(a_, b_) for a_, b_ in zip(outs[0], outs[2]))))
         if "flat" in what:
             from insar_unet_ca_amd._lib import ptr
             rows = call("insar_conv3x3_flat_num_mtiles", x.ref)
