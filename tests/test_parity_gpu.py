@@ -70,6 +70,36 @@ def _halo_abs(a):
 # ------------------------------------------------------------------------------------------------
 # kernel level: implicit GEMM forward / dgrad / wgrad, transposed conv — tight, no ReLU involved
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cin,cout,shape", [(128, 128, (4, 128, 128, 128)), (64, 128, (3, 64, 100, 90)), (128, 64, (2, 128, 256, 256))])
+def test_flat_kernel_pingpong_is_bitwise_the_plain_loop(dev, cin, cout, shape):
+    """conv3x3_flat's ping-pong tap steps (flip bit 1) against its plain loop: forward with BatchNorm partial sums and
+    input gradient, bit for bit, 20 times over."""
+    from insar_unet_ca_amd import _lib, engine
+    from insar_unet_ca_amd._lib import call, ptr
+    dtype = torch.bfloat16
+    ctx = engine.Ctx(dev, dtype)
+    b, _, h, w = shape
+    xa = _act_from(cf.make_input_random(shape, seed=5), dtype, dev)
+    ga = _act_from(cf.make_input_random((b, cout, h, w), seed=6), dtype, dev)
+    assert call("insar_conv3x3_flat_ok", xa.ref, cout) == 1
+    gw = engine.GemmWeight(ctx, torch.nn.Parameter(cf.fill_tensor("weight", (cout, cin, 3, 3), 11).to(dev)), "conv3")
+    wf, wd = gw.fwd(), gw.dgrad()
+    rows = call("insar_conv3x3_flat_num_mtiles", xa.ref)
+    ref = None
+    for pp, reps in ((0, 1), (2, 20)):
+        for _ in range(reps):
+            ya = engine.Act.alloc(b, h, w, cout, dtype, dev)
+            dxa = engine.Act.alloc(b, h, w, cin, dtype, dev)
+            stats = torch.zeros(rows, 2, cout, device=dev)
+            call("insar_conv3x3_flat", xa.ref, ya.ref, ptr(wf), 0 | pp, ptr(stats), _lib.stream_ptr())
+            call("insar_conv3x3_flat", ga.ref, dxa.ref, ptr(wd), 1 | pp, 0, _lib.stream_ptr())
+            if ref is None:
+                ref = (ya.buf.clone(), dxa.buf.clone(), stats.clone())
+                assert float(ref[0].float().abs().max()) > 0
+            else:
+                assert torch.equal(ya.buf, ref[0]) and torch.equal(dxa.buf, ref[1]) and torch.equal(stats, ref[2])
+
+
 @pytest.mark.parametrize("cin,cout,shape", [(64, 512, (2, 64, 128, 128)), (256, 64, (4, 256, 128, 128)), (256, 256, (16, 256, 64, 64)),
                                             (1024, 256, (16, 1024, 32, 32))])
 def test_pingpong_k_loop_is_bitwise_the_plain_loop(dev, cin, cout, shape, monkeypatch):
