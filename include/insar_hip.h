@@ -356,11 +356,17 @@ int insar_cam_excite(const InsarCam* d, void* stream);
 int insar_cam_bwd_coef(const InsarCam* d, const float* red /*[B][rows][2][C]*/, int32_t rows, void* stream);
 int insar_cam_scatter_max(const InsarAct* dx, const float* dmax, const int32_t* arg, void* stream);
 
-/* ---- MaxPool2d(2) (:106-109) -------------------------------------------------------------------- */
+/* ---- MaxPool2d(2) (:106-109): y is the (H/2, W/2) grid rounded down (an odd last row / column belongs to no window) ---- */
 int insar_maxpool2_fwd(const InsarAct* x, const InsarAct* y, void* stream);
 /* dx (+)= route(dy) to the first maximum in scan order (torch semantics). */
 int insar_maxpool2_bwd(const InsarAct* x, const InsarAct* dy, const InsarAct* dx, int32_t accumulate,
                        void* stream);
+
+/* ---- F_T.resize(x, size, BILINEAR) of an NHWC slice (:138-139,144-145,150-151,156-157: the decoder's fallback for tile
+ * sizes that are not multiples of 16), bilinear with align_corners = False, and its adjoint. src / dst: any two grids with
+ * the same batch, channel slice width and dtype. */
+int insar_resize_bilinear_fwd(const InsarAct* src, const InsarAct* dst, void* stream);
+int insar_resize_bilinear_bwd(const InsarAct* ddst, const InsarAct* dsrc, void* stream);
 
 /* ---- outc: Conv2d(64, num_classes, 1) (:125,162) ------------------------------------------------ */
 int insar_conv1x1_out_fwd(const InsarAct* x, const float* w /*(K,C)*/, const float* bias,

@@ -135,6 +135,8 @@ _SIGNATURES = {
     "insar_cam_excite": [C.POINTER(InsarCam), _P],
     "insar_cam_bwd_coef": [C.POINTER(InsarCam), _P, _I, _P],
     "insar_cam_scatter_max": [_AP, _P, _P, _P],
+    "insar_resize_bilinear_fwd": [_AP, _AP, _P],
+    "insar_resize_bilinear_bwd": [_AP, _AP, _P],
     "insar_maxpool2_fwd": [_AP, _AP, _P],
     "insar_maxpool2_bwd": [_AP, _AP, _AP, _I, _P],
     "insar_conv1x1_out_fwd": [_AP, _P, _P, _P, _I, _P],

@@ -1519,9 +1519,10 @@ __global__ void maxpool2_bwd_kernel(ActView x, ActView dy, ActView dx, int accum
   }
 }
 
+// nn.MaxPool2d(2) floors: an odd last row / column of the input belongs to no window
 static int check_pool(const InsarAct* x, const InsarAct* y, const char* who) {
-  if (x->B != y->B || x->H != 2 * y->H || x->W != 2 * y->W || x->c_len != y->c_len || x->dtype != y->dtype)
-    INSAR_FAIL(INSAR_E_SHAPE, "%s: pooled grid must be exactly half of the input grid", who);
+  if (x->B != y->B || y->H != x->H / 2 || y->W != x->W / 2 || y->H < 1 || y->W < 1 || x->c_len != y->c_len || x->dtype != y->dtype)
+    INSAR_FAIL(INSAR_E_SHAPE, "%s: pooled grid must be (H/2, W/2) of the input grid, rounded down", who);
   return INSAR_OK;
 }
 
@@ -1545,11 +1546,137 @@ extern "C" int insar_maxpool2_bwd(const InsarAct* x, const InsarAct* dy, const I
   if ((rc = insar_check_act(dx, "insar_maxpool2_bwd", "dx"))) return rc;
   if ((rc = check_pool(x, dy, "insar_maxpool2_bwd"))) return rc;
   if ((rc = check_same_grid(x, dx, "insar_maxpool2_bwd"))) return rc;
+  if (!accumulate && ((x->H | x->W) & 1))
+    INSAR_FAIL(INSAR_E_SHAPE, "insar_maxpool2_bwd: an odd grid's last row / column belongs to no window: accumulate into a defined dx");
   int grid = insar_grid_cap((int64_t)dy->B * dy->H);
   hipStream_t s = (hipStream_t)stream;
   if (x->dtype == INSAR_BF16) hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*x), make_view(*dy), make_view(*dx), accumulate);
   else hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*x), make_view(*dy), make_view(*dx), accumulate);
   INSAR_CHECK_LAUNCH("insar_maxpool2_bwd");
+  return INSAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bilinear resize of an NHWC slice, align_corners = False: the reference's fallback for tile sizes that are not
+// multiples of 16 (Unet-ChannalAttention.py:138-139,144-145,150-151,156-157: F_T.resize(x, size=skip, BILINEAR) of the
+// transposed-conv output, one pixel larger than 2 x the pooled size), and its adjoint (gather form, deterministic).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rs_coef(int o, float scale, int in, int& i0, int& i1, float& l1) {
+  float src = ((float)o + 0.5f) * scale - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + 1 < in ? i0 + 1 : in - 1;
+  l1 = src - (float)i0;
+}
+
+template <typename T>
+__global__ void resize_fwd_kernel(ActView src, ActView dst, float sh, float sw) {
+  constexpr int CH = Chunk<T>::N;
+  const int cpp = dst.c_len / CH;
+  const int total = dst.W * cpp;
+  for (int r = blockIdx.x; r < dst.B * dst.H; r += gridDim.x) {
+    const int n = r / dst.H, h = r - n * dst.H;
+    int h0, h1; float lh;
+    rs_coef(h, sh, src.H, h0, h1, lh);
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+      const int w = e / cpp, cc = e - w * cpp;
+      int w0, w1; float lw;
+      rs_coef(w, sw, src.W, w0, w1, lw);
+      float a[CH], b[CH], c[CH], d[CH], o[CH];
+      Chunk<T>::unpack(*chunk_ptr<T>(src, n, h0, w0, cc), a);
+      Chunk<T>::unpack(*chunk_ptr<T>(src, n, h0, w1, cc), b);
+      Chunk<T>::unpack(*chunk_ptr<T>(src, n, h1, w0, cc), c);
+      Chunk<T>::unpack(*chunk_ptr<T>(src, n, h1, w1, cc), d);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const float top = (1.f - lw) * a[j] + lw * b[j], bot = (1.f - lw) * c[j] + lw * d[j];
+        o[j] = (1.f - lh) * top + lh * bot;
+      }
+      *chunk_ptr_w<T>(dst, n, h, w, cc) = Chunk<T>::pack(o);
+    }
+  }
+}
+
+template <typename T>
+__global__ void resize_bwd_kernel(ActView ddst, ActView dsrc, float sh, float sw) {
+  constexpr int CH = Chunk<T>::N;
+  const int cpp = dsrc.c_len / CH;
+  const int total = dsrc.W * cpp;
+  for (int r = blockIdx.x; r < dsrc.B * dsrc.H; r += gridDim.x) {
+    const int n = r / dsrc.H, hi = r - n * dsrc.H;
+    int ho_lo = (int)floorf(((float)hi - 0.5f) / sh - 0.5f) - 1, ho_hi = (int)ceilf(((float)hi + 1.5f) / sh - 0.5f) + 1;
+    if (hi == 0) ho_lo = 0;
+    if (hi == dsrc.H - 1) ho_hi = ddst.H - 1;
+    ho_lo = ho_lo < 0 ? 0 : ho_lo; ho_hi = ho_hi > ddst.H - 1 ? ddst.H - 1 : ho_hi;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+      const int wi = e / cpp, cc = e - wi * cpp;
+      int wo_lo = (int)floorf(((float)wi - 0.5f) / sw - 0.5f) - 1, wo_hi = (int)ceilf(((float)wi + 1.5f) / sw - 0.5f) + 1;
+      if (wi == 0) wo_lo = 0;
+      if (wi == dsrc.W - 1) wo_hi = ddst.W - 1;
+      wo_lo = wo_lo < 0 ? 0 : wo_lo; wo_hi = wo_hi > ddst.W - 1 ? ddst.W - 1 : wo_hi;
+      float acc[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) acc[j] = 0.f;
+      for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+        int h0, h1; float lh;
+        rs_coef(ho, sh, dsrc.H, h0, h1, lh);
+        float wh = 0.f;
+        if (h0 == hi) wh += 1.f - lh;
+        if (h1 == hi) wh += lh;
+        if (wh == 0.f) continue;
+        for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+          int w0, w1; float lw;
+          rs_coef(wo, sw, dsrc.W, w0, w1, lw);
+          float ww = 0.f;
+          if (w0 == wi) ww += 1.f - lw;
+          if (w1 == wi) ww += lw;
+          if (ww == 0.f) continue;
+          float g[CH];
+          Chunk<T>::unpack(*chunk_ptr<T>(ddst, n, ho, wo, cc), g);
+          const float k = wh * ww;
+#pragma unroll
+          for (int j = 0; j < CH; ++j) acc[j] = fmaf(k, g[j], acc[j]);
+        }
+      }
+      *chunk_ptr_w<T>(dsrc, n, hi, wi, cc) = Chunk<T>::pack(acc);
+    }
+  }
+}
+
+static int check_resize(const InsarAct* a, const InsarAct* b, const char* who) {
+  if (a->B != b->B || a->c_len != b->c_len || a->dtype != b->dtype) INSAR_FAIL(INSAR_E_SHAPE, "%s: batch / channels / dtype differ", who);
+  const int ch = a->dtype == INSAR_BF16 ? 8 : 4;
+  if (a->c_len % ch) INSAR_FAIL(INSAR_E_SHAPE, "%s: C=%d unsupported", who, a->c_len);
+  return INSAR_OK;
+}
+
+extern "C" int insar_resize_bilinear_fwd(const InsarAct* src, const InsarAct* dst, void* stream) {
+  int rc;
+  if ((rc = insar_check_act(src, "insar_resize_bilinear_fwd", "src"))) return rc;
+  if ((rc = insar_check_act(dst, "insar_resize_bilinear_fwd", "dst"))) return rc;
+  if ((rc = check_resize(src, dst, "insar_resize_bilinear_fwd"))) return rc;
+  int grid = insar_grid_cap((int64_t)dst->B * dst->H);
+  hipStream_t s = (hipStream_t)stream;
+  const float sh = (float)src->H / (float)dst->H, sw = (float)src->W / (float)dst->W;
+  if (src->dtype == INSAR_BF16) hipLaunchKernelGGL(resize_fwd_kernel<bf16_t>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*src), make_view(*dst), sh, sw);
+  else hipLaunchKernelGGL(resize_fwd_kernel<float>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*src), make_view(*dst), sh, sw);
+  INSAR_CHECK_LAUNCH("insar_resize_bilinear_fwd");
+  return INSAR_OK;
+}
+
+/* dsrc = adjoint of insar_resize_bilinear_fwd applied to ddst (the gradient of the resized tensor) */
+extern "C" int insar_resize_bilinear_bwd(const InsarAct* ddst, const InsarAct* dsrc, void* stream) {
+  int rc;
+  if ((rc = insar_check_act(ddst, "insar_resize_bilinear_bwd", "ddst"))) return rc;
+  if ((rc = insar_check_act(dsrc, "insar_resize_bilinear_bwd", "dsrc"))) return rc;
+  if ((rc = check_resize(ddst, dsrc, "insar_resize_bilinear_bwd"))) return rc;
+  int grid = insar_grid_cap((int64_t)dsrc->B * dsrc->H);
+  hipStream_t s = (hipStream_t)stream;
+  const float sh = (float)dsrc->H / (float)ddst->H, sw = (float)dsrc->W / (float)ddst->W;
+  if (dsrc->dtype == INSAR_BF16) hipLaunchKernelGGL(resize_bwd_kernel<bf16_t>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*ddst), make_view(*dsrc), sh, sw);
+  else hipLaunchKernelGGL(resize_bwd_kernel<float>, dim3(grid), dim3(PW_THREADS), 0, s, make_view(*ddst), make_view(*dsrc), sh, sw);
+  INSAR_CHECK_LAUNCH("insar_resize_bilinear_bwd");
   return INSAR_OK;
 }
 

@@ -561,6 +561,11 @@ class ConvBN:
 
     def apply(self, dst: Act, gate: Optional[torch.Tensor], pooled: Optional[Act] = None,
               pool_arg: Optional[torch.Tensor] = None) -> None:
+        if pooled is not None and ((self.y.H | self.y.W) & 1):
+            # odd grid (tile size not a multiple of 16): nn.MaxPool2d(2) drops the last row / column; two passes
+            call("insar_bn_relu_apply", self.y.ref, ptr(self.scale), ptr(self.shift), ptr(gate), dst.ref, 1, _lib.stream_ptr())
+            call("insar_maxpool2_fwd", dst.ref, pooled.ref, _lib.stream_ptr())
+            return
         if pooled is not None:          # encoder block: the 2x2 max-pool of dst comes out of the same pass
             if pool_arg is not None:    # ... with its arg-max map, for the backward passes of this unit
                 call("insar_bn_relu_apply_pool_arg", self.y.ref, ptr(self.scale), ptr(self.shift), ptr(gate), dst.ref,
@@ -806,8 +811,17 @@ class UpPlan:
         if self.cin % 64 or self.cout % 64:
             raise _lib.InsarError(f"{name}: channels must be multiples of 64 on the HIP path")
         self.w = GemmWeight(ctx, mod.weight, "convT")
-        self.bias_rpp = _rows_per_part(out.B, out.H)
-        self.bias_rows = out.B * -(-out.H // self.bias_rpp)
+        # The transposed conv produces (2h, 2w); the skip it is concatenated with may be one pixel larger (tile sizes that
+        # are not multiples of 16): the reference then resizes bilinearly to the skip's size (:138-139 ...). `conv_out` is
+        # where the GEMM writes: the concat slice itself, or a (2h, 2w) buffer that is resized into it.
+        self.resize = (out.H, out.W) != (2 * x.H, 2 * x.W)
+        if self.resize and not (2 * x.H <= out.H <= 2 * x.H + 1 and 2 * x.W <= out.W <= 2 * x.W + 1):
+            raise _lib.InsarError(f"{name}: output {out.H}x{out.W} is not the skip size of a {x.H}x{x.W} input")
+        self.conv_out = Act.alloc(x.B, 2 * x.H, 2 * x.W, self.cout, ctx.dtype, ctx.device) if self.resize else out
+        self.dconv_out = None
+        out_h = self.conv_out.H
+        self.bias_rpp = _rows_per_part(out.B, out_h)
+        self.bias_rows = out.B * -(-out_h // self.bias_rpp)
         self.bias_part = ctx.f32(self.bias_rows, 2, self.cout)
         self.bias_sum = ctx.f32(2, self.cout)
 
@@ -816,13 +830,21 @@ class UpPlan:
 
     def forward(self) -> None:
         self.ctx.join_side()
-        _igemm(self.x, self.out, self.w.fwd(), 4 * self.cout, self.x.H, self.x.W, 1, [(0, 0)], 1,
+        _igemm(self.x, self.conv_out, self.w.fwd(), 4 * self.cout, self.x.H, self.x.W, 1, [(0, 0)], 1,
                bias=self.mod.bias.detach() if self.mod.bias is not None else None)
+        if self.resize:
+            call("insar_resize_bilinear_fwd", self.conv_out.ref, self.out.ref, _lib.stream_ptr())
 
     def backward(self, dout: Act, sink: GradSink, dx: Optional[Act]) -> None:
         """dout: gradient slice wrt this layer's output (upper half of the dcat buffer)."""
         ctx, s = self.ctx, _lib.stream_ptr()
         x, B, h, w = self.x, self.x.B, self.x.H, self.x.W
+        if self.resize:              # gradient of the (2h, 2w) conv output = adjoint of the bilinear resize
+            if self.dconv_out is None:
+                co = self.conv_out
+                self.dconv_out = Act.alloc(co.B, co.H, co.W, co.c_len, ctx.dtype, ctx.device)
+            call("insar_resize_bilinear_bwd", dout.ref, self.dconv_out.ref, s)
+            dout = self.dconv_out
         tabx = ctx.pixel_table(B, h, w, 1, h, w, 0)
         tabdy = ctx.pixel_table(B, h, w, 2, dout.H, dout.W, 0)
         mpad = tabx.numel()
@@ -942,10 +964,8 @@ class UNetPlan:
     """All buffers + the launch sequence of UNet.forward / backward for one input geometry."""
 
     def __init__(self, net, B: int, H: int, W: int, dtype: torch.dtype, device: torch.device):
-        if H % 16 or W % 16:
-            raise _lib.InsarError(
-                f"H={H}, W={W}: the HIP path covers tile sizes that are multiples of 16 (the reference's "
-                "bilinear-resize fallback, Unet-ChannalAttention.py:138-139, is not part of the hot path)")
+        if H < 16 or W < 16:
+            raise _lib.InsarError(f"H={H}, W={W}: four MaxPool2d(2) stages need at least 16 x 16 pixels")
         self.net, self.B, self.H, self.W = net, B, H, W
         ctx = self.ctx = Ctx(device, dtype)
         widths = [net.inc.double_conv[0].out_channels]
@@ -954,6 +974,8 @@ class UNetPlan:
             widths.append(d[1].double_conv[0].out_channels)
         self.widths = widths
         cin = net.inc.double_conv[0].in_channels
+        # nn.MaxPool2d(2) floors; when H or W is not a multiple of 16 some level is odd and the decoder's transposed conv
+        # comes out one pixel short of its skip: the reference's bilinear-resize fallback (:138-139 ...), see UpPlan
         hs = [H >> l for l in range(5)]
         ws = [W >> l for l in range(5)]
         A = lambda l, c: Act.alloc(B, hs[l], ws[l], c, dtype, device)
@@ -978,7 +1000,7 @@ class UNetPlan:
             if l < 4:
                 self.enc[l].pool_out = self.pooled[l]
                 ch = 16 // ctx.esize
-                if POOL_FUSE and widths[l] % ch == 0 and 256 % (widths[l] // ch) == 0:
+                if POOL_FUSE and widths[l] % ch == 0 and 256 % (widths[l] // ch) == 0 and not ((hs[l] | ws[l]) & 1):
                     self.enc[l].pool_arg = torch.zeros((B, hs[l + 1], ws[l + 1], widths[l]), dtype=torch.uint8, device=device)
         ups = [net.up1, net.up2, net.up3, net.up4]
         convs = [net.conv1, net.conv2, net.conv3, net.conv4]

@@ -135,10 +135,12 @@ def double_conv(x, sd, prefix: str, use_se: bool, training: bool,
 
 
 def unet_forward(sd, x: torch.Tensor, use_se: bool = True, training: bool = True) -> torch.Tensor:
-    """UNet.forward, Unet-ChannalAttention.py:127-163 (H, W multiples of 16: the
-    bilinear-resize fallback at :138-139 etc. is never taken)."""
-    if x.shape[2] % 16 or x.shape[3] % 16:
-        raise ValueError("oracle covers only H, W multiples of 16 (no resize fallback)")
+    """UNet.forward, Unet-ChannalAttention.py:127-163. For H, W multiples of 16 the bilinear-resize fallback
+    (:138-139,144-145,150-151,156-157) is never taken and everything here is pinned by the golden vectors. For other sizes
+    the fallback `F_T.resize(x, size, interpolation=BILINEAR)` runs on a tensor: torchvision implements that as
+    torch.nn.functional.interpolate(x, size, mode="bilinear", align_corners=False[, antialias]) — antialiasing only acts
+    when DOWN-scaling, and here the map grows by one pixel — restated below; torchvision is absent from the build container
+    (SURVEY 8c), so this branch is parity-UNPINNED."""
     skips = []
     h = double_conv(x, sd, "inc", use_se, training)
     for i in range(1, 5):
@@ -147,6 +149,8 @@ def unet_forward(sd, x: torch.Tensor, use_se: bool = True, training: bool = True
         h = double_conv(h, sd, f"down{i}.1", use_se, training)
     for i in range(1, 5):
         h = F.conv_transpose2d(h, sd[f"up{i}.weight"], sd[f"up{i}.bias"], stride=2)   # :112..
+        if h.shape[2:] != skips[4 - i].shape[2:]:                      # :138-139 (resize fallback)
+            h = F.interpolate(h, size=tuple(skips[4 - i].shape[2:]), mode="bilinear", align_corners=False)
         h = torch.cat([skips[4 - i], h], dim=1)                        # skip first, :140
         h = double_conv(h, sd, f"conv{i}", use_se, training)
     return F.conv2d(h, sd["outc.weight"], sd["outc.bias"])            # :125,162

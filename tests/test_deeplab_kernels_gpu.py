@@ -208,3 +208,30 @@ def test_conv_unit_against_float64(dev, dtype, k, stride, dil, cin, cout, shape)
     # halos stay zero
     t = dx2.buf.float().clone(); t[:, 1:-1, 1:-1] = 0
     assert float(t.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("hw_in,hw_out", [((4, 6), (5, 7)), ((24, 46), (25, 47)), ((8, 8), (8, 9))])
+def test_nhwc_bilinear_resize_and_floor_pooling(dev, dtype, hw_in, hw_out):
+    """insar_resize_bilinear_fwd / _bwd on padded NHWC slices (the U-Net decoder's one-pixel resize) against
+    F.interpolate and its autograd adjoint; MaxPool2d(2) on an odd grid floors."""
+    from insar_unet_ca_amd import _lib, engine
+    from insar_unet_ca_amd._lib import call
+    s = _lib.stream_ptr()
+    x = _rnd((2, 64) + hw_in, 31, dtype)
+    xa = _act(x, dtype, dev)
+    ya = engine.Act.alloc(2, hw_out[0], hw_out[1], 64, dtype, dev)
+    call("insar_resize_bilinear_fwd", xa.ref, ya.ref, s)
+    xr = x.double().requires_grad_(True)
+    ref = F.interpolate(xr, size=hw_out, mode="bilinear", align_corners=False)
+    assert max_rel(ya.nchw(), ref.detach()) <= TOL[dtype]
+    g = _rnd((2, 64) + hw_out, 32, dtype)
+    ga = _act(g, dtype, dev)
+    dxa = engine.Act.alloc(2, hw_in[0], hw_in[1], 64, dtype, dev)
+    call("insar_resize_bilinear_bwd", ga.ref, dxa.ref, s)
+    ref.backward(g.double())
+    assert max_rel(dxa.nchw(), xr.grad) <= TOL[dtype]
+    # floor pooling of the (odd) resized grid
+    pa = engine.Act.alloc(2, hw_out[0] // 2, hw_out[1] // 2, 64, dtype, dev)
+    call("insar_maxpool2_fwd", ya.ref, pa.ref, s)
+    assert torch.equal(pa.nchw().cpu(), F.max_pool2d(ya.nchw().cpu(), 2))

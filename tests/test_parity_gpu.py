@@ -1152,15 +1152,74 @@ def test_full_size_properties_bf16(dev):
 def test_errors_on_device(dev):
     import insar_unet_ca_amd as iu
     net = iu.UNet(2, 2, True).to(dev)
-    with pytest.raises(iu.InsarError, match="multiples of 16"):
-        net(torch.zeros(1, 2, 40, 40, device=dev))
+    with pytest.raises(iu.InsarError, match="at least 16"):
+        net(torch.zeros(1, 2, 12, 40, device=dev))
     with pytest.raises(iu.InsarError):
         iu.DoubleConv(48, 64).to(dev)(torch.zeros(1, 48, 16, 16, device=dev))
+    with pytest.raises(iu.InsarError, match="input tensor"):
+        net(torch.zeros(1, 2, 32, 32, device=dev, requires_grad=True))
     # forward under no_grad twice, then a normal step: plans are reusable
     with torch.no_grad():
         a = net.eval()(torch.zeros(1, 2, 32, 32, device=dev))
         b = net(torch.zeros(1, 2, 32, 32, device=dev))
     assert torch.equal(a, b)
+    # a frozen parameter gets no gradient (AccumulateGrad semantics); a sub-module in another BatchNorm mode is refused
+    net.train()
+    net.outc.bias.requires_grad_(False)
+    iu.CrossEntropyLoss(ignore_index=255)(net(torch.zeros(2, 2, 32, 32, device=dev)), torch.zeros(2, 32, 32, dtype=torch.long, device=dev)).backward()
+    assert net.outc.bias.grad is None and net.outc.weight.grad is not None
+    net.down1.eval()
+    with pytest.raises(iu.InsarError, match="mixed BatchNorm modes"):
+        net(torch.zeros(2, 2, 32, 32, device=dev))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 2, 40, 56), (1, 2, 100, 100), (2, 2, 33, 47)])
+def test_tile_sizes_that_are_not_multiples_of_16(dev, shape, dtype):
+    """The reference's fallback for such sizes (Unet-ChannalAttention.py:138-139,144-145,150-151,156-157): MaxPool2d(2)
+    floors, the transposed conv comes out one pixel short of its skip and is resized bilinearly to it. Against the oracle's
+    restatement of that branch (parity unpinned there: the reference's F_T.resize is torchvision's, absent here): logits,
+    loss, BatchNorm buffers, and every parameter gradient by norm; the layers next to the loss tightly."""
+    import insar_unet_ca_amd as iu
+    net = iu.UNet(2, 2, True, compute_dtype=dtype)
+    sd = cf.fill_state_dict_random(net.state_dict(), seed=7)
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    x = cf.make_input_random(shape, seed=21)
+    tgt = cf.make_target_random((shape[0], shape[2], shape[3]), seed=22, ignore_frac=0.03)
+    names = [k for k in sd if orc.is_param(k)]
+    work = OrderedDict((k, v.clone()) for k, v in sd.items())
+    leaves = []
+    for k in names:
+        work[k] = work[k].requires_grad_(True)
+        leaves.append(work[k])
+    ref = orc.unet_forward(work, x, use_se=True, training=True)
+    ref_loss = orc.cross_entropy(ref, tgt)
+    grads = dict(zip(names, torch.autograd.grad(ref_loss, leaves)))
+    logits = net(x.to(dev))
+    assert logits.shape == ref.shape
+    loss = iu.CrossEntropyLoss(ignore_index=255)(logits, tgt.to(dev))
+    loss.backward()
+    fp32 = dtype == torch.float32
+    err = max_rel(logits, ref)
+    print(f"{shape} {dtype}: logits max-rel {err:.3e}, loss {float(loss.detach()):.6f} vs {float(ref_loss):.6f}")
+    assert err <= (FWD_TOL if fp32 else BF16_FWD_TOL)
+    assert abs(float(loss.detach()) - float(ref_loss)) <= (1e-4 if fp32 else 2e-2)
+    if not fp32:
+        assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+        return
+    for k, b in net.named_buffers():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert max_rel(b, work[k]) <= 1e-4, k
+    got = dict(net.named_parameters())
+    for k in names:
+        if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
+            assert float(got[k].grad.abs().max()) == 0.0
+            continue
+        nrm = float(grads[k].double().norm())
+        assert abs(float(got[k].grad.double().norm()) - nrm) <= 5e-2 * nrm, k
+    for k in ("outc.weight", "outc.bias", "up4.weight", "up4.bias", "up1.bias"):
+        assert rel_l2(got[k].grad, grads[k]) <= 5e-3, (k, rel_l2(got[k].grad, grads[k]))
 
 
 def test_train_and_validate_loop_mirrors_reference(dev, golden, tmp_path):
