@@ -130,10 +130,28 @@ def test_plan_launch_sequence(mocked_abi):
     assert plan.sink.active != first                    # live .grad aliases buffer 0 -> buffer 1 is used
 
 
+def test_plan_for_a_tile_size_that_is_not_a_multiple_of_16(mocked_abi):
+    """40 x 56: levels 40x56, 20x28, 10x14, 5x7, 2x3. Level 3 is odd: its max-pool floors (stand-alone pool launches instead
+    of the fused BatchNorm passes) and up1's 4x6 output is resized to the 5x7 skip (Unet-ChannalAttention.py:138-139)."""
+    net = iu.UNet(2, 2, True)
+    x = torch.zeros(2, 2, 40, 56)
+    y = net(x)
+    assert y.shape == (2, 2, 40, 56)
+    y.sum().backward()
+    c = collections.Counter(mocked_abi)
+    assert c["insar_resize_bilinear_fwd"] == 1 and c["insar_resize_bilinear_bwd"] == 1
+    assert c["insar_maxpool2_fwd"] == 1 and c["insar_maxpool2_bwd"] == 1
+    assert c["insar_bn_relu_apply_pool_arg"] == 3 and c["insar_bnrelu_bwd_reduce_pool"] == 3
+    plan = net._plan(x)
+    assert [u.resize for u in plan.up] == [True, False, False, False]
+    assert (plan.up[0].conv_out.H, plan.up[0].conv_out.W, plan.up[0].out.H, plan.up[0].out.W) == (4, 6, 5, 7)
+    assert (plan.x5.H, plan.x5.W) == (2, 3)
+
+
 def test_plan_rejects_shapes_outside_the_hot_path(mocked_abi):
     net = iu.UNet(2, 2, True)
-    with pytest.raises(iu.InsarError, match="multiples of 16"):
-        net(torch.zeros(1, 2, 100, 100))
+    with pytest.raises(iu.InsarError, match="at least 16"):
+        net(torch.zeros(1, 2, 100, 12))
     with pytest.raises(iu.InsarError, match="input channels"):
         net(torch.zeros(1, 3, 32, 32))
 
