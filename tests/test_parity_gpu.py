@@ -148,6 +148,8 @@ def test_pingpong_k_loop_is_bitwise_the_plain_loop(dev, cin, cout, shape, monkey
     (128, 128, (2, 128, 24, 128)),   # row-of-taps weight gradient, 128 x 128 tile with 8 waves, two K steps per row
     (64, 512, (2, 64, 128, 128)),    # forward N = 512 on 128 M tiles: 256 x 256 tiles (bf16)
     (256, 64, (4, 256, 128, 128)),   # input gradient N = 256 on 256 M tiles: 256 x 256 tiles (bf16)
+    (128, 64, (2, 128, 64, 64)),     # row-of-taps weight gradient, 128 x 64 tile
+    (64, 64, (2, 64, 32, 32)),       # row-of-taps weight gradient with two image rows per K step
 ])
 def test_igemm_family_against_float64(dev, dtype, cin, cout, shape):
     from insar_unet_ca_amd import engine
