@@ -29,6 +29,7 @@ struct FlatArgs {
   int Cx, cx_off, K;
   int Cy, cy_off, N;
   int kc_count, flip;
+  int abl;                     // ABLATION (temporary): 1 = no global stores/stats, 2 = no main loop, 4 = no MFMA
   int num_mtiles, num_ntiles;
 };
 
@@ -97,18 +98,21 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
   const long long q0 = (long long)mtile * FL_STEP - 1;      // tile row r <-> padded pixel q0 + r
   const int Pm1 = (int)(a.P - 1);
 
-  if (tid < FL_BM) {
-    const long long q = q0 + tid;
-    long long ro = -1;
-    if (tid >= 1 && tid <= FL_STEP && q >= 0 && q < a.P) {
-      const int img = (a.H + 2) * Wp;
-      const int n = (int)(q / img);
-      const int rem = (int)(q - (long long)n * img);
-      const int hr = rem / Wp, wc = rem - hr * Wp;
-      if (hr >= 1 && hr <= a.H && wc >= 1 && wc <= a.W) ro = q * a.Cy + a.cy_off;
+  // output offsets of the tile's rows: computed AFTER the first LDS-DMA pieces are issued (below), under their flight
+  auto fill_row_out = [&]() {
+    if (tid < FL_BM) {
+      const int q = (int)q0 + tid;                            // P < 2^31 (checked by the host side)
+      long long ro = -1;
+      if (tid >= 1 && tid <= FL_STEP && q >= 0 && q <= Pm1) {
+        const int img = (a.H + 2) * Wp;
+        const int n = q / img;
+        const int rem = q - n * img;
+        const int hr = rem / Wp, wc = rem - hr * Wp;
+        if (hr >= 1 && hr <= a.H && wc >= 1 && wc <= a.W) ro = (long long)q * a.Cy + a.cy_off;
+      }
+      rowOut[tid] = ro;
     }
-    rowOut[tid] = ro;
-  }
+  };
 
   // staging geometry (chunk c = i*512 + tid -> LDS row c>>3, lane-linear position c&7)
   const int srow = tid >> 3;                                 // + 64*i
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
   const int swb = r16 & 7;
   const int arow0 = wm * 64 + r16;
 
-  const int kcs = a.kc_count;
+  const int kcs = (a.abl & 2) ? 0 : a.kc_count;
   const int nsteps = kcs * 9, ngroups = kcs * 3;
 
   if constexpr (PP) {
@@ -162,6 +166,7 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
     stageA(0, 0, 0);
     stageB(0, 0, 0);
     stageB(1, 0, 1);
+    fill_row_out();
     fl_wait_and_barrier<0>();           // everything landed; rowOut visible
     if (grp == 1) __builtin_amdgcn_s_barrier();                 // group 1 runs one barrier behind
     for (int kc = 0; kc < kcs; ++kc) {
@@ -209,7 +214,13 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-              for (int mt = 0; mt < MT; ++mt) FMma<T>::run(wf[sub][nt], xf[sub][mt], acc[nt][mt]);
+              for (int mt = 0; mt < MT; ++mt) {
+#ifdef FLAT_ABL_NOMFMA
+                acc[nt][mt][0] += __uint_as_float(wf[sub][nt].x ^ xf[sub][mt].x);
+#else
+                FMma<T>::run(wf[sub][nt], xf[sub][mt], acc[nt][mt]);
+#endif
+              }
           __builtin_amdgcn_s_setprio(0);
           __builtin_amdgcn_sched_barrier(0);
           __builtin_amdgcn_s_barrier();
@@ -222,6 +233,7 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
   stageA(0, 0, 0);
   stageB(0, 0, 0);
   stageB(1, 0, 1);
+  fill_row_out();
   fl_wait_and_barrier<BD>();          // A(0) and B(0) landed, B(1) may still fly; rowOut visible
 
   for (int kc = 0; kc < kcs; ++kc) {
@@ -316,10 +328,10 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
       Chunk<T>::unpack(u, f);
 #pragma unroll
       for (int j = 0; j < CH; ++j) { s1[j] += f[j]; s2[j] = fmaf(f[j], f[j], s2[j]); }
-      *(uint4*)(a.y + (ro + col_off) * ES) = u;
+      if (!(a.abl & 1)) *(uint4*)(a.y + (ro + col_off) * ES) = u;
     }
   }
-  if (a.stats) {
+  if (a.stats && !(a.abl & 1)) {
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
 #pragma unroll
@@ -404,7 +416,7 @@ extern "C" int insar_conv3x3_flat(const InsarAct* x, const InsarAct* y, const vo
   a.P = P; a.B = x->B; a.H = x->H; a.W = x->W;
   a.Cx = x->C; a.cx_off = x->c_off; a.K = x->c_len;
   a.Cy = y->C; a.cy_off = y->c_off; a.N = y->c_len;
-  a.kc_count = x->c_len / bke; a.flip = (flip & 1) ? 1 : 0;
+  a.kc_count = x->c_len / bke; a.flip = (flip & 1) ? 1 : 0; a.abl = (flip >> 4) & 7;
   const bool pp = (flip & 2) != 0;
   a.num_mtiles = flat_mtiles(P);
   hipStream_t s = (hipStream_t)stream;
