@@ -522,8 +522,13 @@ extern "C" int insar_igemm(const InsarIgemm* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const bool wide = igemm_bn_for(a.M, d->N) == 128;
   const bool big = igemm_bm_for(a.M, d->N) == 256;
-  if (oob) {     // dilated taps: two tile shapes per dtype are enough for the DeepLabV3 layers (32x32 maps at B = 16)
-    if (d->x.dtype == INSAR_BF16) return big ? launch_igemm<bf16_t, 256, 64, 3, true>(a, s) : launch_igemm<bf16_t, 128, 64, 2, true>(a, s);
+  if (oob) {     // dilated taps (DeepLabV3's layer3 / layer4 / ASPP, 32x32 maps at B = 16): bf16 follows the tile choice of the
+                 // in-bounds path (ASPP's input gradient has N = 2048: 256 x 256 tiles; layer4's N = 512: 256 x 128), fp32 keeps two shapes
+    if (d->x.dtype == INSAR_BF16) {
+      if (igemm_xwide(a.M, d->N, INSAR_BF16)) return launch_igemm<bf16_t, 256, 256, 2, true>(a, s);
+      if (big) return wide ? launch_igemm<bf16_t, 256, 128, 3, true>(a, s) : launch_igemm<bf16_t, 256, 64, 3, true>(a, s);
+      return launch_igemm<bf16_t, 128, 64, 2, true>(a, s);
+    }
     return big ? launch_igemm<float, 256, 64, 3, true>(a, s) : launch_igemm<float, 128, 64, 2, true>(a, s);
   }
   if (d->x.dtype == INSAR_BF16) {

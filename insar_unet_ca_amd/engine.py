@@ -301,8 +301,8 @@ def _igemm(x: Act, y: Act, w, N: int, Ho: int, Wo: int, stride: int, taps, mode:
         flops = 2.0 * x.B * Ho * Wo * N * x.c_len * len(taps)
         bm = call("insar_igemm_tile_rows", x.B * Ho * Wo, N)
         bn = call("insar_igemm_tile_cols_dt", x.B * Ho * Wo, N, x.code)
-        if oob:
-            bn = 64
+        if oob and x.code == _lib.F32:
+            bn = 64                       # fp32 out-of-bounds variants: 64-column tiles only
         tag = "igemm_kernel<%s, %d, %d, %d%s>" % ("float" if x.code == _lib.F32 else "bf16_t", bm, bn,
                                                   3 if bm == 256 and bn < 256 else 2, ", oob" if oob else "")
         es = 2 if x.code == _lib.BF16 else 4      # operands each read once, output written once
