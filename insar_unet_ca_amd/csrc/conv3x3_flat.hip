@@ -29,7 +29,6 @@ struct FlatArgs {
   int Cx, cx_off, K;
   int Cy, cy_off, N;
   int kc_count, flip;
-  int abl;                     // ABLATION (temporary): 1 = no global stores/stats, 2 = no main loop, 4 = no MFMA
   int num_mtiles, num_ntiles;
 };
 
@@ -157,7 +156,7 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
   const int swb = r16 & 7;
   const int arow0 = wm * 64 + r16;
 
-  const int kcs = (a.abl & 2) ? 0 : a.kc_count;
+  const int kcs = a.kc_count;
   const int nsteps = kcs * 9, ngroups = kcs * 3;
 
   if constexpr (PP) {
@@ -214,13 +213,7 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-              for (int mt = 0; mt < MT; ++mt) {
-#ifdef FLAT_ABL_NOMFMA
-                acc[nt][mt][0] += __uint_as_float(wf[sub][nt].x ^ xf[sub][mt].x);
-#else
-                FMma<T>::run(wf[sub][nt], xf[sub][mt], acc[nt][mt]);
-#endif
-              }
+              for (int mt = 0; mt < MT; ++mt) FMma<T>::run(wf[sub][nt], xf[sub][mt], acc[nt][mt]);
           __builtin_amdgcn_s_setprio(0);
           __builtin_amdgcn_sched_barrier(0);
           __builtin_amdgcn_s_barrier();
@@ -328,10 +321,10 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
       Chunk<T>::unpack(u, f);
 #pragma unroll
       for (int j = 0; j < CH; ++j) { s1[j] += f[j]; s2[j] = fmaf(f[j], f[j], s2[j]); }
-      if (!(a.abl & 1)) *(uint4*)(a.y + (ro + col_off) * ES) = u;
+      *(uint4*)(a.y + (ro + col_off) * ES) = u;
     }
   }
-  if (a.stats && !(a.abl & 1)) {
+  if (a.stats) {
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
 #pragma unroll
@@ -416,7 +409,7 @@ extern "C" int insar_conv3x3_flat(const InsarAct* x, const InsarAct* y, const vo
   a.P = P; a.B = x->B; a.H = x->H; a.W = x->W;
   a.Cx = x->C; a.cx_off = x->c_off; a.K = x->c_len;
   a.Cy = y->C; a.cy_off = y->c_off; a.N = y->c_len;
-  a.kc_count = x->c_len / bke; a.flip = (flip & 1) ? 1 : 0; a.abl = (flip >> 4) & 7;
+  a.kc_count = x->c_len / bke; a.flip = (flip & 1) ? 1 : 0;
   const bool pp = (flip & 2) != 0;
   a.num_mtiles = flat_mtiles(P);
   hipStream_t s = (hipStream_t)stream;

@@ -82,14 +82,6 @@ def main():
                 f = sorted(v[0] for v in rounds[pp]); d = sorted(v[1] for v in rounds[pp])
                 res.append(f"flat pp{pp}: fwd min {f[0]:6.1f} med {f[len(f)//2]:6.1f} us ({flops/f[0]/1e6:6.0f} TF) dgrad min {d[0]:6.1f} med {d[len(d)//2]:6.1f} us ({flops/d[0]/1e6:6.0f} TF)")
             res.append("bitwise=" + str(all(torch.equal(a_, b_) for a_, b_ in zip(outs[0], outs[2]))))
-        if "fabl" in what:     # ablation of the flat kernel (temporary debug bits of `flip`: 16 no stores, 32 no main loop, 64 no MFMA)
-            from insar_unet_ca_amd._lib import ptr
-            rows = call("insar_conv3x3_flat_num_mtiles", x.ref)
-            st2 = torch.zeros(rows, 2, cout, device=dev)
-            for nm, ab in (("full", 0), ("no-stores", 16), ("no-mainloop", 32), ("no-mainloop,no-stores", 48)):
-                f = run(lambda: call("insar_conv3x3_flat", x.ref, y.ref, ptr(wf), 0 | 2 | ab, ptr(st2), _lib.stream_ptr()))
-                d = run(lambda: call("insar_conv3x3_flat", g.ref, dx.ref, ptr(wd), 1 | 2 | ab, 0, _lib.stream_ptr()))
-                res.append(f"\n   {nm:24s} fwd {f:7.1f} us  dgrad {d:7.1f} us")
         if "flat" in what:
             from insar_unet_ca_amd._lib import ptr
             rows = call("insar_conv3x3_flat_num_mtiles", x.ref)
