@@ -37,6 +37,14 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
   __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
   return __builtin_bit_cast(uint16_t, h);
 }
+// two values -> one packed dword (lo in bits 0-15) as ONE v_cvt_pk_bf16_f32: written with scalar conversions and shifts
+// hipcc pairs the conversions across dwords and repairs the halves with and / shl / or (6-8 VALU per 4 values instead of 2)
+typedef float insar_f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 insar_bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+  const insar_f32x2_t f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, insar_bf16x2_t));
+}
 
 // 16-byte chunk <-> float lanes
 template <typename T> struct Chunk;
@@ -59,10 +67,8 @@ template <> struct Chunk<bf16_t> {
   }
   __device__ __forceinline__ static uint4 pack(const float* f) {
     uint4 u;
-    u.x = (uint32_t)f32_to_bf16(f[0]) | ((uint32_t)f32_to_bf16(f[1]) << 16);
-    u.y = (uint32_t)f32_to_bf16(f[2]) | ((uint32_t)f32_to_bf16(f[3]) << 16);
-    u.z = (uint32_t)f32_to_bf16(f[4]) | ((uint32_t)f32_to_bf16(f[5]) << 16);
-    u.w = (uint32_t)f32_to_bf16(f[6]) | ((uint32_t)f32_to_bf16(f[7]) << 16);
+    u.x = pack2_bf16(f[0], f[1]); u.y = pack2_bf16(f[2], f[3]);
+    u.z = pack2_bf16(f[4], f[5]); u.w = pack2_bf16(f[6], f[7]);
     return u;
   }
 };

@@ -140,10 +140,8 @@ __global__ __launch_bounds__(C6_THREADS, 1) void conv3x3_c64_kernel(C64Args a) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
           uint2 v;
-          const uint16_t b0 = f32_to_bf16(acc[nt][mt][0]), b1 = f32_to_bf16(acc[nt][mt][1]);
-          const uint16_t b2 = f32_to_bf16(acc[nt][mt][2]), b3 = f32_to_bf16(acc[nt][mt][3]);
-          v.x = (uint32_t)b0 | ((uint32_t)b1 << 16);
-          v.y = (uint32_t)b2 | ((uint32_t)b3 << 16);
+          v.x = pack2_bf16(acc[nt][mt][0], acc[nt][mt][1]);
+          v.y = pack2_bf16(acc[nt][mt][2], acc[nt][mt][3]);
           *(uint2*)(yp + nt * 32) = v;
           const float f0 = __uint_as_float(v.x << 16), f1 = __uint_as_float(v.x & 0xffff0000u);
           const float f2 = __uint_as_float(v.y << 16), f3 = __uint_as_float(v.y & 0xffff0000u);

@@ -187,13 +187,13 @@ __global__ void __launch_bounds__(DR_THREADS) conv3x3_small_fwd_mfma_kernel(ActV
         d_f32x4_t acc = (d_f32x4_t){0.f, 0.f, 0.f, 0.f};
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[nt], xf, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf, acc, 0, 0, 0);
-        const uint16_t b0 = f32_to_bf16(acc[0]), b1 = f32_to_bf16(acc[1]), b2 = f32_to_bf16(acc[2]), b3 = f32_to_bf16(acc[3]);
         if (ok) {
           uint2 v;
-          v.x = (uint32_t)b0 | ((uint32_t)b1 << 16);
-          v.y = (uint32_t)b2 | ((uint32_t)b3 << 16);
+          v.x = pack2_bf16(acc[0], acc[1]);
+          v.y = pack2_bf16(acc[2], acc[3]);
           *(uint2*)(yp + nt * 32) = v;
-          const float f0 = bf16_to_f32(b0), f1 = bf16_to_f32(b1), f2 = bf16_to_f32(b2), f3 = bf16_to_f32(b3);
+          const float f0 = __uint_as_float(v.x << 16), f1 = __uint_as_float(v.x & 0xffff0000u);
+          const float f2 = __uint_as_float(v.y << 16), f3 = __uint_as_float(v.y & 0xffff0000u);
           s1[nt][0] += f0; s2[nt][0] = fmaf(f0, f0, s2[nt][0]);
           s1[nt][1] += f1; s2[nt][1] = fmaf(f1, f1, s2[nt][1]);
           s1[nt][2] += f2; s2[nt][2] = fmaf(f2, f2, s2[nt][2]);

@@ -337,8 +337,8 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
       char* p = tile + row * Cfg::PITCH + col * ES;
       if constexpr (ES == 2) {
         uint2 v;
-        v.x = (uint32_t)f32_to_bf16(acc[nt][mt][0]) | ((uint32_t)f32_to_bf16(acc[nt][mt][1]) << 16);
-        v.y = (uint32_t)f32_to_bf16(acc[nt][mt][2]) | ((uint32_t)f32_to_bf16(acc[nt][mt][3]) << 16);
+        v.x = pack2_bf16(acc[nt][mt][0], acc[nt][mt][1]);
+        v.y = pack2_bf16(acc[nt][mt][2], acc[nt][mt][3]);
         *(uint2*)p = v;
       } else {
         *(f32x4_t*)p = acc[nt][mt];
