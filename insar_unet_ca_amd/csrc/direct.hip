@@ -435,6 +435,157 @@ __global__ void __launch_bounds__(DR_THREADS) conv3x3_small_wgrad_kernel(ActView
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same weight gradient on the matrix cores (bf16, Cin = 2, Cout = 64, W % 64 == 0: the U-Net's first layer,
+// Unet-ChannalAttention.py:81 under loss.backward()). As a GEMM over pixels,
+//     D[m][co] = sum_pix P[pix][m] * dY[pix][co],     m = 2 * tap + ci  (18 of 32 rows used),
+// with P the im2col patch matrix, which is never in memory: every WAVE owns K steps of 64 consecutive pixels of one
+// image row; per step it stages its dY tile (64 x 128 B) by LDS-DMA into one of two wave-private slots, writes the
+// 64 x 32 patch tile from nine 4-byte loads a lane (lane = pixel) and feeds v_mfma_f32_16x16x32_bf16 through
+// transposing LDS reads (the reduction dimension, pixels, is the row index of both tiles), as csrc/wgrad3.hip does.
+// No work-group barrier in the loop (tiles are wave-private; a wave's own vmcnt / lgkmcnt waits order them); the VALU
+// version spends 144 FMAs a chunk and is bound by them (90 us for 134 MB of dY), this one by HBM.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short d_s16x4_t;
+#define SWM_WAVES 4
+#define SWM_Y_TILE (64 * 128)        // dY tile: 64 pixel rows x 64 channels (bf16)
+#define SWM_P_TILE (64 * 64)         // patch tile: 64 pixel rows x 32 columns (bf16)
+#define SWM_WAVE_LDS (2 * SWM_Y_TILE + SWM_P_TILE)
+
+struct SmallWgradMfmaArgs {
+  const char* x; const char* dy; float* part;
+  int H, W, Wp, spr;                 // spr = W / 64 K steps per image row
+  int Cx, cx_off, Cdy, cdy_off;
+  int ksteps;                        // B * H * spr
+};
+
+__global__ __launch_bounds__(SWM_WAVES * 64, 2) void conv3x3_small_wgrad_mfma_kernel(SmallWgradMfmaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  char* sW = smem + wave * SWM_WAVE_LDS;                       // this wave's slots: Y0 | Y1 | P
+  char* sP = sW + 2 * SWM_Y_TILE;
+  const uint32_t ldsW = lds_offset_of(sW);
+  const int r16 = lane & 15, kq = lane >> 4;
+
+  // this wave's K steps: a contiguous range
+  const int gw = blockIdx.x * SWM_WAVES + wave, GW = gridDim.x * SWM_WAVES;
+  const int ks0 = (int)((long long)gw * a.ksteps / GW), ks1 = (int)((long long)(gw + 1) * a.ksteps / GW);
+
+  // patch tile: zero once (columns 18..31 stay zero; 0..17 are rewritten every step)
+  {
+    uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *(uint4*)(sP + lane * 64 + c * 16) = z;
+  }
+  // padded index of the first pixel of K step ks
+  auto first_pixel = [&](int ks) -> long long {
+    const int g = ks / a.spr, seg = ks - g * a.spr;           // g = image row over the batch
+    const int img = g / a.H, h = g - img * a.H;
+    return ((long long)img * (a.H + 2) + h + 1) * a.Wp + seg * 64 + 1;
+  };
+  // dY tile by LDS-DMA: instruction i covers rows 8i .. 8i+7 (lane -> row 8i + lane/8, 16-byte chunk lane%8), XOR-swizzled
+  // on the source side exactly as wgrad3.hip's 128-byte rows
+  const int yrow = lane >> 3, ypos = lane & 7;
+  const long long ypitch = (long long)a.Cdy * 2, xpitch = (long long)a.Cx * 2;
+  const char* ybase = a.dy + (long long)a.cdy_off * 2;
+  const char* xbase = a.x + (long long)a.cx_off * 2;
+  auto stage_y = [&](int buf, long long p0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = i * 8 + yrow;
+      lds_dma16_untracked(ybase + (p0 + row) * ypitch + ((ypos ^ (((row >> 1) & 3) << 1)) << 4), ldsW + buf * SWM_Y_TILE + i * 1024);
+    }
+  };
+  uint32_t xq[9];
+  auto load_x = [&](long long p0) {
+    const char* xc = xbase + (p0 + lane) * xpitch;            // this lane's pixel; taps at uniform offsets
+#pragma unroll
+    for (int t = 0; t < 9; ++t) xq[t] = *(const uint32_t*)(xc + ((t / 3 - 1) * a.Wp + (t % 3 - 1)) * xpitch);
+  };
+
+  d_f32x4_t acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (d_f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  if (ks0 < ks1) {
+    const long long p0 = first_pixel(ks0);
+    stage_y(0, p0);
+    load_x(p0);
+  }
+  const int pswz = (lane >> 2) & 3;                             // patch-tile swizzle of this lane's row (row = lane)
+  for (int ks = ks0; ks < ks1; ++ks) {
+    const int buf = (ks - ks0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this step's dY tile and x values have landed
+    // patch row of this lane's pixel: dword t = (x[pix + tap t][0], x[..][1]) -> columns 2t, 2t+1; 16-byte chunks XOR-swizzled.
+    // The x values are consumed BEFORE the next step's loads are issued: hipcc counts only its own loads, so a use after the
+    // (inline-asm) LDS-DMA issue would make it wait for the next tile as well.
+#pragma unroll
+    for (int t = 0; t < 9; ++t) *(uint32_t*)(sP + lane * 64 + (((t >> 2) ^ pswz) << 4) + (t & 3) * 4) = xq[t];
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 1 < ks1) {                                         // next step's loads fly during this step's LDS reads and MFMAs
+      const long long p1 = first_pixel(ks + 1);
+      stage_y(buf ^ 1, p1);
+      load_x(p1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the tile is this wave's own: no barrier
+    const char* sY = sW + buf * SWM_Y_TILE;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      d_bf16x8_t yf[4], pf[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int sel = h ^ (kq & 1);
+        const int row = s2 * 32 + kq * 8 + sel * 4 + (r16 >> 2);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int colb = (nt * 16 + (r16 & 3) * 4) * 2;
+          const char* q = sY + row * 128 + (((colb >> 4) ^ (((row >> 1) & 3) << 1)) << 4) + (colb & 15);
+          d_s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) d_s16x4_t*)q);
+          yf[nt][4 * h + 0] = v[0]; yf[nt][4 * h + 1] = v[1]; yf[nt][4 * h + 2] = v[2]; yf[nt][4 * h + 3] = v[3];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int colb = (mt * 16 + (r16 & 3) * 4) * 2;
+          const char* q = sP + row * 64 + (((colb >> 4) ^ ((row >> 2) & 3)) << 4) + (colb & 15);
+          d_s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) d_s16x4_t*)q);
+          pf[mt][4 * h + 0] = v[0]; pf[mt][4 * h + 1] = v[1]; pf[mt][4 * h + 2] = v[2]; pf[mt][4 * h + 3] = v[3];
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[mt], yf[nt], acc[mt][nt], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // reads done before the next step rewrites the patch tile
+  }
+
+  // fold the four waves' partial D (C layout: row m = kq*4 + reg, column co = r16) and write this block's row of `part`
+  // in torch order: part[block][(co * 2 + ci) * 9 + tap], m = 2 * tap + ci
+  __syncthreads();
+  float* red = (float*)smem;                                    // [wave][m 32][co 64]
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[(wave * 32 + mt * 16 + kq * 4 + j) * 64 + nt * 16 + r16] = acc[mt][nt][j];
+  __syncthreads();
+  for (int o = threadIdx.x; o < 18 * 64; o += blockDim.x) {
+    const int m = o / 64, co = o - m * 64;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < SWM_WAVES; ++w) v += red[(w * 32 + m) * 64 + co];
+    a.part[(long long)blockIdx.x * (64 * 2 * 9) + (co * 2 + (m & 1)) * 9 + (m >> 1)] = v;
+  }
+}
+
+static inline bool small_wgrad_uses_mfma(const InsarAct* x, const InsarAct* dy) {
+  return dy->dtype == INSAR_BF16 && dy->c_len == 64 && x->c_len == 2 && (x->W % 64) == 0 && (x->C % 2) == 0 &&
+         (x->c_off % 2) == 0 && (dy->C % 8) == 0 && (dy->c_off % 8) == 0;
+}
+
 extern "C" int insar_conv3x3_small_wgrad_blocks(int32_t B, int32_t H) {
   int64_t r = (int64_t)B * H;
   return (int)(r > 512 ? 512 : r);
@@ -449,6 +600,22 @@ extern "C" int insar_conv3x3_small_wgrad(const InsarAct* x, const InsarAct* dy, 
   size_t lds = (size_t)4 * cpp * 9 * ch * sizeof(float);
   int grid = insar_conv3x3_small_wgrad_blocks(dy->B, dy->H);
   hipStream_t s = (hipStream_t)stream;
+  if (small_wgrad_uses_mfma(x, dy)) {
+    static std::atomic<uint64_t> attr_mask{0};     // per-device, see common.h
+    const int lds_bytes = SWM_WAVES * SWM_WAVE_LDS;
+    hipError_t e = insar_set_lds_once(attr_mask, (const void*)conv3x3_small_wgrad_mfma_kernel, lds_bytes);
+    if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_conv3x3_small_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    SmallWgradMfmaArgs a;
+    a.x = (const char*)x->ptr; a.dy = (const char*)dy->ptr; a.part = part;
+    a.H = x->H; a.W = x->W; a.Wp = x->W + 2; a.spr = x->W / 64;
+    a.Cx = x->C; a.cx_off = x->c_off; a.Cdy = dy->C; a.cdy_off = dy->c_off;
+    const long long ksteps = (long long)x->B * x->H * a.spr;
+    if (ksteps > 0x7fffffffLL) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_small_wgrad: too many pixels");
+    a.ksteps = (int)ksteps;
+    hipLaunchKernelGGL(conv3x3_small_wgrad_mfma_kernel, dim3(grid), dim3(SWM_WAVES * 64), lds_bytes, s, a);
+    INSAR_CHECK_LAUNCH("insar_conv3x3_small_wgrad");
+    return INSAR_OK;
+  }
   const bool pair = (x->c_len % 2) == 0 && (x->C % 2) == 0 && (x->c_off % 2) == 0;      // aligned 2-channel loads
   if (dy->dtype == INSAR_BF16) {
     if (pair) hipLaunchKernelGGL((conv3x3_small_wgrad_kernel<bf16_t, 2>), dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), make_view(*dy), part);

@@ -287,6 +287,36 @@ def test_first_layer_conv_against_float64(dev, dtype, cin, shape):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,shape", [
+    (2, (2, 2, 24, 128)),    # bf16: the matrix-core kernel (W % 64 == 0), two K steps per image row
+    (2, (1, 2, 5, 64)),      # fewer K steps than waves: most waves fold an empty partial sum
+    (2, (3, 2, 16, 192)),    # three K steps per row, three images
+    (2, (3, 2, 24, 40)),     # W % 64 != 0: the VALU kernel (packed FMAs, prefetched items)
+    (1, (2, 1, 16, 64)),     # one input channel: VALU kernel in both dtypes
+    (4, (2, 4, 16, 32)),
+])
+def test_first_layer_weight_gradient_against_float64(dev, dtype, cin, shape):
+    """dW of the first conv (Cin <= 4): per-block partial rows folded by insar_colsum, against float64 on the operands
+    exactly as the kernel saw them."""
+    from insar_unet_ca_amd import _lib, engine
+    from insar_unet_ca_amd._lib import call, ptr
+    b, _, h, w = shape
+    ctx = engine.Ctx(dev, dtype)
+    xa = _act_from(cf.make_input(shape, 0.3), dtype, dev)
+    ga = _act_from(cf.make_grad((b, 64, h, w)), dtype, dev)
+    nb = call("insar_conv3x3_small_wgrad_blocks", b, h)
+    cols = 64 * cin * 9
+    part = torch.full((nb, cols), float("nan"), device=dev)
+    call("insar_conv3x3_small_wgrad", xa.ref, ga.ref, ptr(part), _lib.stream_ptr())
+    gw = torch.zeros(64, cin, 3, 3, device=dev)
+    ctx.colsum(part, gw, 1, nb, cols)
+    xr = xa.nchw().cpu().double()
+    wv = torch.zeros(64, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, wv, padding=1).backward(ga.nchw().cpu().double())
+    assert max_rel(gw, wv.grad) <= KERNEL_TOL * 5            # fp32 accumulation in both dtypes
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_weight_relayout_single_and_batched(dev, dtype):
     """GEMM-operand forms of Conv2d / ConvTranspose2d weights: the per-weight kernel and the one-launch
     paired kernel (both forms from one read) give exactly the permutations of the fp32 master."""
