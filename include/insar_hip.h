@@ -322,9 +322,12 @@ int insar_bn_relu_apply_outc(const InsarAct* y, const float* scale, const float*
                              void* stream);
 int insar_conv1x1_out_wgrad_y(const InsarAct* y, const float* scale, const float* shift, const float* gate /*nullable*/,
                               const float* w, const float* dlogits, int32_t K, float* part, void* stream);
+/* wpart (nullable; gate [B][C] nullable): the same pass also writes the output conv's parameter-gradient partials,
+ * wpart[B * ceil(H / rows_per_part)][K*C + K] in the layout of insar_conv1x1_out_wgrad_y's `part` (fold with insar_colsum):
+ * the weight gradient of the output conv then needs no pass of its own over y. */
 int insar_bnrelu_bwd_reduce_outc(const float* dlogits, const float* wout, int32_t K, const InsarAct* y,
                                  const float* scale, const float* shift, float* part, int32_t relu,
-                                 int32_t rows_per_part, void* stream);
+                                 int32_t rows_per_part, const float* gate, float* wpart, void* stream);
 int insar_bnrelu_bwd_apply_outc(const float* dlogits, const float* wout, int32_t K, const InsarAct* y,
                                 const float* scale, const float* shift, const float* mean, const float* invstd,
                                 const float* gate, const float* coefB, const float* k1, const float* k2,

@@ -127,7 +127,7 @@ _SIGNATURES = {
     "insar_conv1x1_out_wgrad": [_AP, _P, _P, _I, _P, _P],
     "insar_bn_relu_apply_outc": [_AP, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "insar_conv1x1_out_wgrad_y": [_AP, _P, _P, _P, _P, _P, _I, _P, _P],
-    "insar_bnrelu_bwd_reduce_outc": [_P, _P, _I, _AP, _P, _P, _P, _I, _I, _P],
+    "insar_bnrelu_bwd_reduce_outc": [_P, _P, _I, _AP, _P, _P, _P, _I, _I, _P, _P, _P],
     "insar_bnrelu_bwd_apply_outc": [_P, _P, _I, _AP, _P, _P, _P, _P, _P, _P, _P, _P, _AP, _I, _P],
     "insar_bnse_bwd_coef_stage": [C.POINTER(InsarBnSeBwd), _P, _I, _P, _P, _P, _P, _I, _I, _P],
     "insar_bnrelu_bwd_apply_part": [_AP, _AP, _P, _P, _P, _P, _P, _P, _P, _P, _AP, _I, _P],

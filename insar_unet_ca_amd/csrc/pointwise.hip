@@ -748,6 +748,11 @@ struct OutcGrad {
   const float* dl;      // [B][K][H][W] fp32, or null: read the gradient tensor
   const float* w;       // [K][C] fp32
   int K;
+  // reduce pass only, nullable: also produce the 1x1 output conv's own parameter gradients from the same read of y —
+  // wpart[part row][K*C + K] = (sum dl[k] * z[c], sum dl[k]) over the row part, z = round_T(relu(y*scale+shift) * gate[n])
+  // (the arithmetic of conv1x1_out_bwd_kernel<T, true>, csrc/direct.hip); gate [B][C] or null
+  const float* gate;
+  float* wpart;
 };
 template <typename T, int KM>
 __device__ __forceinline__ void outc_grad_chunk(const float (&dlv)[KM], const float (&wk)[KM][Chunk<T>::N], int K,
@@ -802,6 +807,19 @@ __global__ void __launch_bounds__((VK || VP) ? 512 : 1024) row_reduce_kernel(Act
       }
       const int64_t HW = (int64_t)y.H * y.W;
       const int wstep = blockDim.x / cpp;
+      // (virt, og.wpart) the output conv's weight / bias gradient of this row part
+      const bool wgrad = virt && og.wpart != nullptr;
+      float aw[KM][CH], ab[KM], zg[CH];
+      if constexpr (virt) {
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+          ab[k] = 0.f;
+#pragma unroll
+          for (int j = 0; j < CH; ++j) aw[k][j] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) zg[j] = (wgrad && og.gate) ? og.gate[(int64_t)n * y.c_len + cc * CH + j] : 1.f;
+      }
       for (int h = h0; h < h1; ++h) {
         for (int w0 = threadIdx.x / cpp; w0 < y.W; w0 += PW_UNROLL * wstep) {
           uint4 vy[PW_UNROLL], vg[PW_UNROLL], vp[VP ? PW_UNROLL : 1];
@@ -837,6 +855,24 @@ __global__ void __launch_bounds__((VK || VP) ? 512 : 1024) row_reduce_kernel(Act
                 const float m = WITH_G ? (on ? gg[j] : 0.f) : (on ? 1.f : 0.f);
                 a0[j] += m; a1[j] = fmaf(m, f[j], a1[j]);
               }
+              if constexpr (virt) {
+                if (wgrad) {
+                  float zz[CH], zr[CH];
+#pragma unroll
+                  for (int j = 0; j < CH; ++j) {
+                    const float t = fmaf(f[j], sc[j], sh[j]);
+                    zz[j] = (relu ? fmaxf(t, 0.f) : t) * zg[j];
+                  }
+                  Chunk<T>::unpack(Chunk<T>::pack(zz), zr);        // the rounding the stored activation would have had
+#pragma unroll
+                  for (int k = 0; k < KM; ++k)
+                    if (k < og.K) {
+#pragma unroll
+                      for (int j = 0; j < CH; ++j) aw[k][j] = fmaf(dlv[u][k], zr[j], aw[k][j]);
+                      if (cc == 0) ab[k] += dlv[u][k];
+                    }
+                }
+              }
             }
         }
       }
@@ -852,6 +888,31 @@ __global__ void __launch_bounds__((VK || VP) ? 512 : 1024) row_reduce_kernel(Act
         part[((int64_t)r * 2 + q) * y.c_len + c] = s;
       }
       __syncthreads();
+      if constexpr (virt) {
+        if (wgrad) {
+          const int pw = og.K * y.c_len + og.K;
+#pragma unroll
+          for (int k = 0; k < KM; ++k)
+            if (k < og.K) {
+#pragma unroll
+              for (int j = 0; j < CH; ++j) red[threadIdx.x][j] = aw[k][j];
+              red[threadIdx.x][CH] = ab[k];
+              __syncthreads();
+              for (int o = threadIdx.x; o <= y.c_len; o += blockDim.x) {
+                float s = 0.f;
+                if (o < y.c_len) {
+                  const int occ = o / CH, j = o - occ * CH;
+                  for (int t = occ; t < blockDim.x; t += cpp) s += red[t][j];
+                  og.wpart[(int64_t)r * pw + k * y.c_len + o] = s;
+                } else {
+                  for (int t = 0; t < blockDim.x; t += cpp) s += red[t][CH];
+                  og.wpart[(int64_t)r * pw + og.K * y.c_len + k] = s;
+                }
+              }
+              __syncthreads();
+            }
+        }
+      }
     } else {
       // generic (slow) path: thread per channel
       for (int c = threadIdx.x; c < y.c_len; c += blockDim.x) {
@@ -886,8 +947,8 @@ extern "C" int insar_se_squeeze(const InsarAct* y, const float* scale, const flo
   int grid = insar_grid_cap((int64_t)y->B * ((y->H + rpp - 1) / rpp));
   hipStream_t s = (hipStream_t)stream;
   ActView v = make_view(*y);
-  if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, false>), dim3(grid), dim3(PW_THREADS), 0, s, v, v, scale, shift, part, relu, rpp, OutcGrad{nullptr, nullptr, 0}, PoolGrad{ActView{}, nullptr});
-  else hipLaunchKernelGGL((row_reduce_kernel<float, false>), dim3(grid), dim3(PW_THREADS), 0, s, v, v, scale, shift, part, relu, rpp, OutcGrad{nullptr, nullptr, 0}, PoolGrad{ActView{}, nullptr});
+  if (y->dtype == INSAR_BF16) hipLaunchKernelGGL((row_reduce_kernel<bf16_t, false>), dim3(grid), dim3(PW_THREADS), 0, s, v, v, scale, shift, part, relu, rpp, OutcGrad{nullptr, nullptr, 0, nullptr, nullptr}, PoolGrad{ActView{}, nullptr});
+  else hipLaunchKernelGGL((row_reduce_kernel<float, false>), dim3(grid), dim3(PW_THREADS), 0, s, v, v, scale, shift, part, relu, rpp, OutcGrad{nullptr, nullptr, 0, nullptr, nullptr}, PoolGrad{ActView{}, nullptr});
   INSAR_CHECK_LAUNCH("insar_se_squeeze");
   return INSAR_OK;
 }
@@ -945,7 +1006,7 @@ static int launch_bwd_reduce(const char* who, const InsarAct* dout, const InsarA
 extern "C" int insar_bnrelu_bwd_reduce(const InsarAct* dout, const InsarAct* y, const float* scale, const float* shift,
                                        float* part, int32_t relu, int32_t rows_per_part, void* stream) {
   return launch_bwd_reduce("insar_bnrelu_bwd_reduce", dout, y, scale, shift, part, relu, rows_per_part,
-                           OutcGrad{nullptr, nullptr, 0}, PoolGrad{ActView{}, nullptr}, stream);
+                           OutcGrad{nullptr, nullptr, 0, nullptr, nullptr}, PoolGrad{ActView{}, nullptr}, stream);
 }
 
 // The same sums with dout = round(dskip + (arg == position ? dpooled : 0)): the gradient that reaches an encoder block's
@@ -958,19 +1019,22 @@ extern "C" int insar_bnrelu_bwd_reduce_pool(const InsarAct* dskip, const InsarAc
   if ((rc = insar_check_act(y, "insar_bnrelu_bwd_reduce_pool", "y"))) return rc;
   if ((rc = check_pool_grad(y, dpooled, arg, "insar_bnrelu_bwd_reduce_pool"))) return rc;
   return launch_bwd_reduce("insar_bnrelu_bwd_reduce_pool", dskip, y, scale, shift, part, relu, rows_per_part,
-                           OutcGrad{nullptr, nullptr, 0}, PoolGrad{make_view(*dpooled), arg}, stream);
+                           OutcGrad{nullptr, nullptr, 0, nullptr, nullptr}, PoolGrad{make_view(*dpooled), arg}, stream);
 }
 
 // The same sums with dout = gradient of the 1x1 output conv's input, recomputed from dlogits [B][K][H][W] (fp32) and
 // the conv's weight [K][C] instead of read from memory (see OutcGrad above).
+// wpart (nullable, with gate [B][C] nullable): also write the output conv's parameter-gradient partials of every row part,
+// wpart[B * ceil(H / rows_per_part)][K*C + K] in the layout of insar_conv1x1_out_wgrad_y's `part` (insar_colsum folds
+// them): the weight gradient then needs no pass of its own over y.
 extern "C" int insar_bnrelu_bwd_reduce_outc(const float* dlogits, const float* wout, int32_t K, const InsarAct* y,
                                             const float* scale, const float* shift, float* part, int32_t relu,
-                                            int32_t rows_per_part, void* stream) {
+                                            int32_t rows_per_part, const float* gate, float* wpart, void* stream) {
   int rc;
   if ((rc = insar_check_act(y, "insar_bnrelu_bwd_reduce_outc", "y"))) return rc;
   if ((rc = check_outc_grad(y, dlogits, wout, K, "insar_bnrelu_bwd_reduce_outc"))) return rc;
   return launch_bwd_reduce("insar_bnrelu_bwd_reduce_outc", nullptr, y, scale, shift, part, relu, rows_per_part,
-                           OutcGrad{dlogits, wout, K}, PoolGrad{ActView{}, nullptr}, stream);
+                           OutcGrad{dlogits, wout, K, gate, wpart}, PoolGrad{ActView{}, nullptr}, stream);
 }
 
 // Sum `rows` rows of a [rows][cols] fp32 slab into out[cols] (LDS), all threads of the block cooperating:
@@ -1406,7 +1470,7 @@ extern "C" int insar_bnrelu_bwd_apply(const InsarAct* dout, const InsarAct* y, c
                                       const float* mean, const float* invstd, const float* gate, const float* coefB,
                                       const float* k1, const float* k2, const InsarAct* dy, int32_t relu, void* stream) {
   return launch_bwd_apply("insar_bnrelu_bwd_apply", dout, y, scale, shift, mean, invstd, gate, coefB, k1, k2, dy, relu,
-                          nullptr, nullptr, OutcGrad{nullptr, nullptr, 0}, PoolGrad{ActView{}, nullptr}, stream);
+                          nullptr, nullptr, OutcGrad{nullptr, nullptr, 0, nullptr, nullptr}, PoolGrad{ActView{}, nullptr}, stream);
 }
 
 // The same pass with dout = round(dskip + (arg == position ? dpooled : 0)) (see insar_bnrelu_bwd_reduce_pool).
@@ -1418,7 +1482,7 @@ extern "C" int insar_bnrelu_bwd_apply_pool(const InsarAct* dskip, const InsarAct
   if ((rc = insar_check_act(y, "insar_bnrelu_bwd_apply_pool", "y"))) return rc;
   if ((rc = check_pool_grad(y, dpooled, arg, "insar_bnrelu_bwd_apply_pool"))) return rc;
   return launch_bwd_apply("insar_bnrelu_bwd_apply_pool", dskip, y, scale, shift, mean, invstd, gate, coefB, k1, k2, dy, relu,
-                          nullptr, nullptr, OutcGrad{nullptr, nullptr, 0}, PoolGrad{make_view(*dpooled), arg}, stream);
+                          nullptr, nullptr, OutcGrad{nullptr, nullptr, 0, nullptr, nullptr}, PoolGrad{make_view(*dpooled), arg}, stream);
 }
 
 // The same pass with dout = gradient of the 1x1 output conv's input recomputed from dlogits (see OutcGrad above).
@@ -1430,7 +1494,7 @@ extern "C" int insar_bnrelu_bwd_apply_outc(const float* dlogits, const float* wo
   if ((rc = insar_check_act(y, "insar_bnrelu_bwd_apply_outc", "y"))) return rc;
   if ((rc = check_outc_grad(y, dlogits, wout, K, "insar_bnrelu_bwd_apply_outc"))) return rc;
   return launch_bwd_apply("insar_bnrelu_bwd_apply_outc", nullptr, y, scale, shift, mean, invstd, gate, coefB, k1, k2, dy, relu,
-                          nullptr, nullptr, OutcGrad{dlogits, wout, K}, PoolGrad{ActView{}, nullptr}, stream);
+                          nullptr, nullptr, OutcGrad{dlogits, wout, K, nullptr, nullptr}, PoolGrad{ActView{}, nullptr}, stream);
 }
 
 // The same pass with k1 / k2 taken from stage 1's per-image partial sums (ws of insar_bnse_bwd_coef_stage, stage 1):
@@ -1440,7 +1504,7 @@ extern "C" int insar_bnrelu_bwd_apply_part(const InsarAct* dout, const InsarAct*
                                            const float* tb, const float* tg, const InsarAct* dy, int32_t relu, void* stream) {
   if (!tb) INSAR_FAIL(INSAR_E_ARG, "insar_bnrelu_bwd_apply_part: null partial sums");
   return launch_bwd_apply("insar_bnrelu_bwd_apply_part", dout, y, scale, shift, mean, invstd, gate, coefB, nullptr, nullptr, dy,
-                          relu, tb, tg, OutcGrad{nullptr, nullptr, 0}, PoolGrad{ActView{}, nullptr}, stream);
+                          relu, tb, tg, OutcGrad{nullptr, nullptr, 0, nullptr, nullptr}, PoolGrad{ActView{}, nullptr}, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

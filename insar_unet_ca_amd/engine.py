@@ -267,6 +267,7 @@ SPLIT_COEF = os.environ.get("INSAR_SPLIT_COEF", "0") == "1"
 POOL_FUSE = os.environ.get("INSAR_POOL_FUSE", "1") != "0"        # diagnostic: 0 routes the max-pool gradient with insar_maxpool2_bwd
 PREP_SIDE = os.environ.get("INSAR_PREP_SIDE", "1") != "0"         # diagnostic: 0 re-lays the weights out on the main stream
 OUTC_FUSE = os.environ.get("INSAR_OUTC_FUSE", "1") != "0"        # diagnostic: 0 materialises the gradient of outc's input
+OUTC_WGRAD_FUSE = os.environ.get("INSAR_OUTC_WGRAD_FUSE", "1") != "0"   # diagnostic: 0 = outc's weight gradient in its own pass over y
 WGRAD_FILL_T = float(os.environ.get("INSAR_WGRAD_FILL_T", "0.5"))   # the same for the transposed convs' per-tap weight gradient
 WGRAD_FILL_ALONE = float(os.environ.get("INSAR_WGRAD_FILL_ALONE", "1.0"))   # ... and when it has the GPU to itself
 WGRAD_FILL = float(os.environ.get("INSAR_WGRAD_FILL", "0.5"))     # share of the work-group slots a side-stream weight gradient aims at
@@ -600,9 +601,12 @@ class ConvBN:
         if self.dy is None:
             self.dy = Act.alloc(B, H, W, self.cout, ctx.dtype, ctx.device)
         if outc_grad is not None:
-            dl, wout, K = outc_grad
+            # (dlogits, outc weight, K[, gate, wpart]): with wpart the reduce pass also writes the output conv's own
+            # parameter-gradient partials, one row per row part (OutConvPlan.backward_fused folds them)
+            dl, wout, K = outc_grad[:3]
+            og_gate, og_wpart = (outc_grad[3], outc_grad[4]) if len(outc_grad) > 3 else (None, None)
             call("insar_bnrelu_bwd_reduce_outc", ptr(dl), ptr(wout), K, self.y.ref, ptr(self.scale), ptr(self.shift),
-                 ptr(self.red_part), 1, self.red_rpp, s)
+                 ptr(self.red_part), 1, self.red_rpp, ptr(og_gate), ptr(og_wpart), s)
         elif pool_grad is not None:
             # encoder block: dout = skip gradient + the max-pool gradient routed by the forward arg-max map, summed on the fly
             dpool, parg = pool_grad
@@ -889,6 +893,7 @@ class OutConvPlan:
         self.part = ctx.f32(self.nb, self.cols)
         self.folded = ctx.f32(self.cols)
         self.fused_src = None          # (unit, gate) when the last forward went through forward_fused
+        self.part_red, self.reduce_rows = None, 0      # parameter-gradient partials written by the unit's reduce pass
 
     def params(self):
         return [self.mod.weight, self.mod.bias]
@@ -921,6 +926,10 @@ class OutConvPlan:
             if self.mod.bias is not None:
                 sink.view(self.mod.bias).copy_(self.folded[kc:])
 
+        if dx is None and self.reduce_rows:
+            # the parameter-gradient partials come out of the unit's BatchNorm-backward reduce pass (same read of y): only
+            # the fold is left, on the side stream, once that pass has been enqueued (UNetPlan.backward calls fold_fused)
+            return
         if dx is None:
             if self.ctx.side is not None and not (PROFILER is not None and PROFILER.alone) and dlogits.is_cuda:
                 if torch.cuda.is_current_stream_capturing():
@@ -941,6 +950,27 @@ class OutConvPlan:
              ptr(self.part), _lib.stream_ptr())
         with self.ctx.side_stream():            # folds are off the critical path
             fold()
+
+    def fused_grad(self, unit: "ConvBN"):
+        """(gate, wpart) for the unit's reduce pass when outc's parameter gradients are to come out of it (OUTC_WGRAD_FUSE,
+        the fused forward ran, K <= 2: the instantiation that has the registers), else None."""
+        self.reduce_rows = 0
+        if not (OUTC_WGRAD_FUSE and self.fused_src is not None and self.K <= 2 and self.fused_src[0] is unit):
+            return None
+        self.reduce_rows = unit.x.B * unit.red_rows
+        if self.part_red is None or self.part_red.shape[0] != self.reduce_rows:
+            self.part_red = self.ctx.f32(self.reduce_rows, self.cols)
+        return self.fused_src[1], self.part_red
+
+    def fold_fused(self, sink: GradSink) -> None:
+        if not self.reduce_rows:
+            return
+        with self.ctx.side_stream():
+            self.ctx.colsum(self.part_red, self.folded, 1, self.reduce_rows, self.cols)
+            kc = self.K * self.cin
+            sink.view(self.mod.weight).view(-1).copy_(self.folded[:kc])
+            if self.mod.bias is not None:
+                sink.view(self.mod.bias).copy_(self.folded[kc:])
 
     def virtual_grad_ok(self) -> bool:
         ch = 16 // self.ctx.esize
@@ -1066,11 +1096,16 @@ class UNetPlan:
         sink, training, w = self.sink, self.training, self.widths
         sink.select()
         fuse = self.outc.virtual_grad_ok()
+        wg = self.outc.fused_grad(self.dconv[3].u2) if fuse else None
         self.outc.backward(dlogits, sink, None if fuse else self.ddec[0])
         for i in (3, 2, 1, 0):
             l = 3 - i
             og = (dlogits, self.net.outc.weight.detach(), self.outc.K) if (fuse and i == 3) else None
+            if og and wg:
+                og = og + wg
             self.dconv[i].backward(None if og else self.ddec[l], sink, training, self.dcat[l], og)
+            if og and wg:
+                self.outc.fold_fused(sink)
             dsrc = self.dx5 if i == 0 else self.ddec[l + 1]
             self.up[i].backward(self.dcat[l].slice(w[l], w[l]), sink, dsrc)
             if on_bucket is not None:

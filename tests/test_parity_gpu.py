@@ -1070,6 +1070,7 @@ def test_recomputed_outc_gradient_is_bitwise_the_materialised_one(dev, dtype, mo
     x, y = make_batch(7, 3, 48)
     x, y = x.to(dev), y.to(dev)
     grads, outs = [], []
+    monkeypatch.setattr(engine, "OUTC_WGRAD_FUSE", False)      # outc's own weight gradient in its own pass: same summation order
     for fuse in (True, False):
         monkeypatch.setattr(engine, "OUTC_FUSE", fuse)
         torch.manual_seed(11)
@@ -1084,6 +1085,38 @@ def test_recomputed_outc_gradient_is_bitwise_the_materialised_one(dev, dtype, mo
             outs.append((logits.detach().clone(), net(x).clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert all(torch.equal(a, b) for a, b in zip(*grads))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("size", [48, 256])
+def test_outc_weight_gradient_from_the_reduce_pass(dev, dtype, size, monkeypatch):
+    """outc's weight / bias gradient written by the last unit's BatchNorm-backward reduce pass (one read of y for both)
+    against the stand-alone pass over y: every other gradient bitwise equal, outc's own to fp32 summation order."""
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd import engine
+    from insar_unet_ca_amd.data import make_batch
+    x, y = make_batch(7, 3 if size == 48 else 2, size)
+    x, y = x.to(dev), y.to(dev)
+    grads = []
+    for fuse in (True, False):
+        monkeypatch.setattr(engine, "OUTC_WGRAD_FUSE", fuse)
+        torch.manual_seed(11)
+        net = iu.UNet(2, 2, True, compute_dtype=dtype).to(dev).train()
+        calls = []
+        orig = engine.call
+        monkeypatch.setattr(engine, "call", lambda name, *a: (calls.append(name), orig(name, *a))[1])
+        loss = iu.DiceCELoss(ignore_index=255)(net(x), y)
+        loss.backward()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(engine, "call", orig)
+        assert ("insar_conv1x1_out_wgrad_y" in calls) == (not fuse)
+        grads.append({n: p.grad.clone() for n, p in net.named_parameters()})
+    for n in grads[0]:
+        if n.startswith("outc."):
+            assert max_rel(grads[0][n], grads[1][n]) <= 2e-5, n
+            assert float(grads[0][n].abs().max()) > 0
+        else:
+            assert torch.equal(grads[0][n], grads[1][n]), n
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
