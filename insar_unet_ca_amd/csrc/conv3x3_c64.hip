@@ -121,20 +121,28 @@ __global__ __launch_bounds__(C6_THREADS, 1) void conv3x3_c64_kernel(C64Args a) {
   // stores + BatchNorm partial sums (interior pixels only) of the tile whose sums are in `acc`
   auto epilogue = [&](int tile) {
     const int qt = tile * C6_TILE + a.o;
+    // (padded row, padded column) of this lane's first pixel, by reciprocal multiplies (+ one correction step each: exact
+    // for q / img < 2^22 and img < 2^24, which c64_geometry() guarantees), on q + img so that the few negative pixel
+    // indices of the first tile decompose like the others; the other three pixels are 16, 32, 48 further on: one
+    // conditional wrap each instead of the two divisions.
+    int hr, wc;
+    {
+      const int qb = qt + lrow + a.img;
+      const int n = (int)((float)qb * a.inv_img);
+      int rem = qb - n * a.img;
+      if (rem < 0) { rem += a.img; } else if (rem >= a.img) { rem -= a.img; }
+      hr = (int)((float)rem * a.inv_wp);
+      wc = rem - hr * Wp;
+      if (wc < 0) { wc += Wp; --hr; } else if (wc >= Wp) { wc -= Wp; ++hr; }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int q = qt + lrow + mt * 16;
-      bool ok = q >= 0 && q <= Pm1;
-      const int qq = ok ? q : 0;
-      // q -> (image, padded row, padded column) with reciprocal multiplies (+ one correction step each):
-      // exact for q / img < 2^22 and img < 2^24, which c64_geometry() guarantees.
-      int n = (int)((float)qq * a.inv_img);
-      int rem = qq - n * a.img;
-      if (rem < 0) { rem += a.img; } else if (rem >= a.img) { rem -= a.img; }
-      int hr = (int)((float)rem * a.inv_wp);
-      int wc = rem - hr * Wp;
-      if (wc < 0) { wc += Wp; --hr; } else if (wc >= Wp) { wc -= Wp; ++hr; }
-      ok = ok && hr >= 1 && hr <= a.H && wc >= 1 && wc <= a.W;
+      if (mt > 0) {
+        wc += 16;
+        if (wc >= Wp) { wc -= Wp; ++hr; if (hr >= a.H + 2) hr = 0; }
+      }
+      const bool ok = q >= 0 && q <= Pm1 && hr >= 1 && hr <= a.H && wc >= 1 && wc <= a.W;
       if (ok) {
         char* yp = a.y + ((long long)q * a.Cy + a.cy_off + wn * (16 * NTW) + kq * 4) * 2;
 #pragma unroll
