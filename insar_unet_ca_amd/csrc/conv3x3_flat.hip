@@ -29,7 +29,9 @@ struct FlatArgs {
   int Cx, cx_off, K;
   int Cy, cy_off, N;
   int kc_count, flip;
+  int persist;
   int num_mtiles, num_ntiles;
+  int total_tiles;             // num_mtiles * num_ntiles
 };
 
 template <typename T> struct FMma;
@@ -85,9 +87,13 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
   float* sstat = (float*)(smem + Cfg::MAIN + Cfg::ROWINFO);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Work-groups are PERSISTENT when the grid is smaller than the tile count (a.total_tiles; the launch picks the grid):
+  // virtual block vb = blockIdx + k * gridDim walks this work-group's tiles; with gridDim % 8 == 0 it stays on its XCD, so
+  // the XCD-aware tile order below is that of the one-tile-per-work-group launch.
+  for (int vb = blockIdx.x; vb < a.total_tiles; vb += gridDim.x) {
   int t;
   {
-    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int nwg = a.total_tiles, bid = vb;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
@@ -351,6 +357,8 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
       a.stats[((long long)mtile * 2 + 1) * a.N + n0 + tid] = v2;
     }
   }
+  __syncthreads();          // the next tile's LDS-DMA rewrites the ring the epilogue tile aliases
+  }
 }
 
 // ---- host side -----------------------------------------------------------------------------------
@@ -380,7 +388,12 @@ static int launch_flat(FlatArgs& a, hipStream_t s) {
     if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_conv3x3_flat: hipFuncSetAttribute(%d bytes LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
   }
   a.num_ntiles = a.N / BN;
-  const long long grid = (long long)a.num_mtiles * a.num_ntiles;
+  long long grid = (long long)a.num_mtiles * a.num_ntiles;
+  a.total_tiles = (int)grid;
+  if (a.persist) {                                   // one work-group per CU (the LDS allows no more), each walking its tiles
+    const int cus = insar_num_cus() & ~7;
+    if (cus >= 8 && grid > cus) grid = cus;
+  }
   hipLaunchKernelGGL((conv3x3_flat_kernel<T, BN, PP>), dim3((unsigned)grid), dim3(FL_THREADS), Cfg::LDS_BYTES, s, a);
   INSAR_CHECK_LAUNCH("insar_conv3x3_flat");
   return INSAR_OK;
@@ -409,7 +422,7 @@ extern "C" int insar_conv3x3_flat(const InsarAct* x, const InsarAct* y, const vo
   a.P = P; a.B = x->B; a.H = x->H; a.W = x->W;
   a.Cx = x->C; a.cx_off = x->c_off; a.K = x->c_len;
   a.Cy = y->C; a.cy_off = y->c_off; a.N = y->c_len;
-  a.kc_count = x->c_len / bke; a.flip = (flip & 1) ? 1 : 0;
+  a.kc_count = x->c_len / bke; a.flip = (flip & 1) ? 1 : 0; a.persist = (flip & 4) ? 1 : 0;
   const bool pp = (flip & 2) != 0;
   a.num_mtiles = flat_mtiles(P);
   hipStream_t s = (hipStream_t)stream;

@@ -273,6 +273,7 @@ WGRAD_FILL_ALONE = float(os.environ.get("INSAR_WGRAD_FILL_ALONE", "1.0"))   # ..
 WGRAD_FILL = float(os.environ.get("INSAR_WGRAD_FILL", "0.5"))     # share of the work-group slots a side-stream weight gradient aims at
 WGRAD_ROWS = os.environ.get("INSAR_WGRAD_ROWS", "1") != "0"      # diagnostic: 0 = per-tap weight-gradient kernel everywhere
 FLAT_PP = int(os.environ.get("INSAR_FLAT_PP", "1"))               # flat 3x3 kernel: ping-pong tap steps (0 = plain loop; bitwise equal)
+FLAT_PERSIST = int(os.environ.get("INSAR_FLAT_PERSIST", "1"))     # flat 3x3 kernel: one work-group per CU walking its tiles (bitwise equal): 1 = forward launches, 2 = all, 0 = off
 IGEMM_PP = int(os.environ.get("INSAR_IGEMM_PP", "1"))            # 256 x 256 tiles: ping-pong K loop (0 = the plain two-slab loop; bitwise equal)
 WGRAD_LATE = os.environ.get("INSAR_WGRAD_ORDER", "before") == "after"      # diagnostic / tuning switch, see ConvBN.backward
 
@@ -313,13 +314,20 @@ def _igemm(x: Act, y: Act, w, N: int, Ho: int, Wo: int, stride: int, taps, mode:
     call("insar_igemm", C.byref(d), _lib.stream_ptr())
 
 
+def _flat_persist(flip: int) -> bool:
+    """Persistent work-groups for the flat kernel: 1 = forward launches only (default: the input-gradient launches share
+    the chip with the side stream's weight gradients, where a static tile assignment loses to the dispatcher's; same-box
+    A/B in DESIGN.md), 2 = every launch, 0 = never."""
+    return FLAT_PERSIST == 2 or (FLAT_PERSIST == 1 and not (flip & 1))
+
+
 def _conv3x3_flat(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[torch.Tensor]) -> None:
     if PROFILER is not None:
         flops = 2.0 * x.B * x.H * x.W * y.c_len * x.c_len * 9
         tag = "conv3x3_flat_kernel<%s, %d>" % ("float" if x.code == _lib.F32 else "bf16_t", 128 if y.c_len % 128 == 0 else 64)
-        PROFILER.run(tag, flops, lambda: call("insar_conv3x3_flat", x.ref, y.ref, ptr(w), flip | (2 if FLAT_PP else 0), ptr(stats), _lib.stream_ptr()))
+        PROFILER.run(tag, flops, lambda: call("insar_conv3x3_flat", x.ref, y.ref, ptr(w), flip | (2 if FLAT_PP else 0) | (4 if _flat_persist(flip) else 0), ptr(stats), _lib.stream_ptr()))
         return
-    call("insar_conv3x3_flat", x.ref, y.ref, ptr(w), flip | (2 if FLAT_PP else 0), ptr(stats), _lib.stream_ptr())
+    call("insar_conv3x3_flat", x.ref, y.ref, ptr(w), flip | (2 if FLAT_PP else 0) | (4 if _flat_persist(flip) else 0), ptr(stats), _lib.stream_ptr())
 
 
 def _conv3x3_c64(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[torch.Tensor]) -> None:

@@ -72,8 +72,9 @@ def _halo_abs(a):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cin,cout,shape", [(128, 128, (4, 128, 128, 128)), (64, 128, (8, 64, 100, 90)), (128, 64, (2, 128, 256, 256))])
 def test_flat_kernel_pingpong_is_bitwise_the_plain_loop(dev, cin, cout, shape):
-    """conv3x3_flat's ping-pong tap steps (flip bit 1) against its plain loop: forward with BatchNorm partial sums and
-    input gradient, bit for bit, 20 times over."""
+    """conv3x3_flat's ping-pong tap steps (flip bit 1), alone and with persistent work-groups (bit 2: one per CU walking
+    several tiles through the same LDS), against its plain one-tile-per-work-group loop: forward with BatchNorm partial sums
+    and input gradient, bit for bit, 20 times over each."""
     from insar_unet_ca_amd import _lib, engine
     from insar_unet_ca_amd._lib import call, ptr
     dtype = torch.bfloat16
@@ -86,7 +87,7 @@ def test_flat_kernel_pingpong_is_bitwise_the_plain_loop(dev, cin, cout, shape):
     wf, wd = gw.fwd(), gw.dgrad()
     rows = call("insar_conv3x3_flat_num_mtiles", xa.ref)
     ref = None
-    for pp, reps in ((0, 1), (2, 20)):
+    for pp, reps in ((0, 1), (2, 20), (4, 20), (6, 20)):
         for _ in range(reps):
             ya = engine.Act.alloc(b, h, w, cout, dtype, dev)
             dxa = engine.Act.alloc(b, h, w, cin, dtype, dev)

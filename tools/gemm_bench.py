@@ -82,6 +82,18 @@ def main():
                 f = sorted(v[0] for v in rounds[pp]); d = sorted(v[1] for v in rounds[pp])
                 res.append(f"flat pp{pp}: fwd min {f[0]:6.1f} med {f[len(f)//2]:6.1f} us ({flops/f[0]/1e6:6.0f} TF) dgrad min {d[0]:6.1f} med {d[len(d)//2]:6.1f} us ({flops/d[0]/1e6:6.0f} TF)")
             res.append("bitwise=" + str(all(torch.equal(a_, b_) for a_, b_ in zip(outs[0], outs[2]))))
+        if "fpers" in what:    # persistent tile loop of the flat kernel (flip bit 4), same-process A/B, interleaved rounds
+            from insar_unet_ca_amd._lib import ptr
+            rows = call("insar_conv3x3_flat_num_mtiles", x.ref)
+            st2 = torch.zeros(rows, 2, cout, device=dev)
+            rr = {0: [], 4: []}
+            for r in range(4):
+                for pb in (0, 4):
+                    rr[pb].append((run(lambda: call("insar_conv3x3_flat", x.ref, y.ref, ptr(wf), 0 | 2 | pb, ptr(st2), _lib.stream_ptr())),
+                                   run(lambda: call("insar_conv3x3_flat", g.ref, dx.ref, ptr(wd), 1 | 2 | pb, 0, _lib.stream_ptr()))))
+            for pb in (0, 4):
+                f = sorted(v[0] for v in rr[pb]); d = sorted(v[1] for v in rr[pb])
+                res.append(f"\n   persist={pb >> 2}: fwd min {f[0]:6.1f} med {f[len(f)//2]:6.1f} us  dgrad min {d[0]:6.1f} med {d[len(d)//2]:6.1f} us")
         if "flat" in what:
             from insar_unet_ca_amd._lib import ptr
             rows = call("insar_conv3x3_flat_num_mtiles", x.ref)
