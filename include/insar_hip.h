@@ -125,6 +125,9 @@ int insar_igemm(const InsarIgemm* d, void* stream);
  * eligibility heuristic (enough tiles to fill the chip, W,H >= 30). */
 int insar_conv3x3_flat_ok(const InsarAct* x, int32_t N);
 int insar_conv3x3_flat_num_mtiles(const InsarAct* x);
+/* rows of the statistics slab for a launch with these flags: one per M tile, or one per work-group for persistent
+ * work-groups (flip bit 2) with a single N tile, which carry the sums over their tiles */
+int insar_conv3x3_flat_stat_rows(const InsarAct* x, int32_t N, int32_t flip);
 int insar_conv3x3_flat(const InsarAct* x, const InsarAct* y, const void* w, int32_t flip, float* stats,
                        void* stream);
 

@@ -30,6 +30,7 @@ struct FlatArgs {
   int Cy, cy_off, N;
   int kc_count, flip;
   int persist;
+  int carry;                   // persistent + one N tile: BatchNorm sums carried over the tiles, slab row = blockIdx.x
   int num_mtiles, num_ntiles;
   int total_tiles;             // num_mtiles * num_ntiles
 };
@@ -90,6 +91,13 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
   // Work-groups are PERSISTENT when the grid is smaller than the tile count (a.total_tiles; the launch picks the grid):
   // virtual block vb = blockIdx + k * gridDim walks this work-group's tiles; with gridDim % 8 == 0 it stays on its XCD, so
   // the XCD-aware tile order below is that of the one-tile-per-work-group launch.
+  // persistent work-groups with one N tile: the BatchNorm partial sums of all of a work-group's tiles are carried in
+  // registers (a thread owns the same channel chunk in every tile) and folded ONCE, into row blockIdx.x of the slab:
+  // gridDim.x rows instead of one per tile (no pre-fold launch before bn_finalize), no per-tile fold and barrier
+  constexpr int CHc = Chunk<T>::N;
+  float cs1[CHc], cs2[CHc];
+#pragma unroll
+  for (int j = 0; j < CHc; ++j) { cs1[j] = 0.f; cs2[j] = 0.f; }
   for (int vb = blockIdx.x; vb < a.total_tiles; vb += gridDim.x) {
   int t;
   {
@@ -330,7 +338,10 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
       *(uint4*)(a.y + (ro + col_off) * ES) = u;
     }
   }
-  if (a.stats) {
+  if (a.stats && a.carry) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { cs1[j] += s1[j]; cs2[j] += s2[j]; }
+  } else if (a.stats) {
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
 #pragma unroll
@@ -359,6 +370,30 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
   }
   __syncthreads();          // the next tile's LDS-DMA rewrites the ring the epilogue tile aliases
   }
+  if (a.stats && a.carry) {
+    constexpr int CPR = BN * ES / 16;
+    constexpr int CH = CHc;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+#pragma unroll
+      for (int o = CPR; o < 64; o <<= 1) { cs1[j] += __shfl_xor(cs1[j], o, 64); cs2[j] += __shfl_xor(cs2[j], o, 64); }
+    }
+    if (lane < CPR) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        sstat[(wave * BN + lane * CH + j) * 2 + 0] = cs1[j];
+        sstat[(wave * BN + lane * CH + j) * 2 + 1] = cs2[j];
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { v1 += sstat[(w * BN + tid) * 2 + 0]; v2 += sstat[(w * BN + tid) * 2 + 1]; }
+      a.stats[((long long)blockIdx.x * 2 + 0) * a.N + tid] = v1;       // one N tile: n0 = 0
+      a.stats[((long long)blockIdx.x * 2 + 1) * a.N + tid] = v2;
+    }
+  }
 }
 
 // ---- host side -----------------------------------------------------------------------------------
@@ -378,6 +413,17 @@ extern "C" int insar_conv3x3_flat_ok(const InsarAct* x, int32_t N) {
   return (long long)flat_mtiles(P) * (N / bn) >= 256 ? 1 : 0;
 }
 extern "C" int insar_conv3x3_flat_num_mtiles(const InsarAct* x) { return x ? flat_mtiles(flat_pixels(*x)) : 0; }
+// Rows of the statistics slab a launch with these flags writes: one per M tile, or — persistent work-groups (flip bit 2)
+// with one N tile — one per work-group.
+extern "C" int insar_conv3x3_flat_stat_rows(const InsarAct* x, int32_t N, int32_t flip) {
+  if (!x) return 0;
+  const int mt = flat_mtiles(flat_pixels(*x));
+  if (!(flip & 4)) return mt;
+  const int bn = (N % 128) == 0 ? 128 : 64;
+  const int cus = insar_num_cus() & ~7;
+  const long long grid = (long long)mt * (N / bn);
+  return (cus >= 8 && grid > cus && N / bn == 1) ? cus : mt;
+}
 
 template <typename T, int BN, bool PP = false>
 static int launch_flat(FlatArgs& a, hipStream_t s) {
@@ -390,9 +436,10 @@ static int launch_flat(FlatArgs& a, hipStream_t s) {
   a.num_ntiles = a.N / BN;
   long long grid = (long long)a.num_mtiles * a.num_ntiles;
   a.total_tiles = (int)grid;
+  a.carry = 0;
   if (a.persist) {                                   // one work-group per CU (the LDS allows no more), each walking its tiles
     const int cus = insar_num_cus() & ~7;
-    if (cus >= 8 && grid > cus) grid = cus;
+    if (cus >= 8 && grid > cus) { grid = cus; a.carry = a.num_ntiles == 1 ? 1 : 0; }
   }
   hipLaunchKernelGGL((conv3x3_flat_kernel<T, BN, PP>), dim3((unsigned)grid), dim3(FL_THREADS), Cfg::LDS_BYTES, s, a);
   INSAR_CHECK_LAUNCH("insar_conv3x3_flat");

@@ -497,7 +497,7 @@ class ConvBN:
         elif self.c64:
             self.stat_rows = call("insar_igemm_num_mtiles", self.M, self.cout)
         elif self.flat_fwd:
-            self.stat_rows = call("insar_conv3x3_flat_num_mtiles", x.ref)
+            self.stat_rows = call("insar_conv3x3_flat_stat_rows", x.ref, self.cout, 4 if _flat_persist(0) else 0)
         else:
             self.stat_rows = call("insar_igemm_num_mtiles", self.M, self.cout)
         self.stats = ctx.f32(self.stat_rows, 2, self.cout)

@@ -86,7 +86,7 @@ def test_flat_kernel_pingpong_is_bitwise_the_plain_loop(dev, cin, cout, shape):
     gw = engine.GemmWeight(ctx, torch.nn.Parameter(cf.fill_tensor("weight", (cout, cin, 3, 3), 11).to(dev)), "conv3")
     wf, wd = gw.fwd(), gw.dgrad()
     rows = call("insar_conv3x3_flat_num_mtiles", xa.ref)
-    ref = None
+    ref, persistent_stats = None, None
     for pp, reps in ((0, 1), (2, 20), (4, 20), (6, 20)):
         for _ in range(reps):
             ya = engine.Act.alloc(b, h, w, cout, dtype, dev)
@@ -97,6 +97,15 @@ def test_flat_kernel_pingpong_is_bitwise_the_plain_loop(dev, cin, cout, shape):
             if ref is None:
                 ref = (ya.buf.clone(), dxa.buf.clone(), stats.clone())
                 assert float(ref[0].float().abs().max()) > 0
+            elif pp & 4:
+                # persistent work-groups carry the sums over their tiles: one slab row per work-group, the rest untouched
+                assert torch.equal(ya.buf, ref[0]) and torch.equal(dxa.buf, ref[1])
+                prow = call("insar_conv3x3_flat_stat_rows", xa.ref, cout, pp)
+                assert prow <= rows and float(stats[prow:].abs().max() if prow < rows else 0.0) == 0.0
+                assert max_rel(stats.sum(0), ref[2].sum(0)) <= 1e-5
+                if persistent_stats is None:
+                    persistent_stats = {}
+                assert torch.equal(persistent_stats.setdefault(pp, stats.clone()), stats)      # run-to-run: bit for bit
             else:
                 assert torch.equal(ya.buf, ref[0]) and torch.equal(dxa.buf, ref[1]) and torch.equal(stats, ref[2])
 
