@@ -89,3 +89,10 @@ def test_tile_selection_queries_without_a_gpu():
     assert rows(256, 256, 64, 64, BF16) == (64, 64) and rows(64, 64, 512, 256, BF16) == (128, 128)
     assert rows(32, 32, 512, 512, BF16) == (128, 128) and rows(16, 16, 1024, 1024, F32) == (128, 128)
     assert rows(48, 80, 64, 64, BF16) == (0, 0) and rows(3, 16, 64, 64, BF16) == (0, 0)     # per-tap kernel there
+    # statistics slab of the flat 3x3 kernel: one row per M tile; persistent work-groups (flip bit 2) with one N tile carry
+    # the sums over their tiles: one row per work-group (= CUs, 256 when no device answers), unless the grid is smaller
+    big, small = act(256, 256, 128, BF16), act(32, 32, 128, BF16)
+    mt = call("insar_conv3x3_flat_num_mtiles", big)
+    assert mt == (16 * 258 * 258 + 253) // 254
+    assert call("insar_conv3x3_flat_stat_rows", big, 64, 0) == mt and call("insar_conv3x3_flat_stat_rows", big, 64, 4) == 256
+    assert call("insar_conv3x3_flat_stat_rows", small, 64, 4) == call("insar_conv3x3_flat_num_mtiles", small) < 256
