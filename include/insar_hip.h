@@ -119,9 +119,10 @@ int insar_igemm(const InsarIgemm* d, void* stream);
  * input gradient with flip = 1), for large grids: the three dx taps of a dy share one LDS tile of input
  * rows, so A rows cross the L2->LDS path 3 times instead of 9. x and y cover the same B x H x W grid.
  * flip: bit 0 = walk the taps backwards (input gradient); bit 1 = the ping-pong K loop (bf16; same results bit for bit);
- * bit 2 = persistent work-groups (one per CU, each walking its tiles in the same XCD-aware order; same results bit for bit).
+ * bit 2 = persistent work-groups (one per CU, each walking its tiles in the same XCD-aware order; same outputs bit for bit,
+ * the statistics summed per work-group instead of per tile).
  * w: [9][N][K] in the raster order produced by insar_weight_prep; stats (nullable):
- * float[insar_conv3x3_flat_num_mtiles(x)][2][N]. insar_conv3x3_flat_ok() is the library's own
+ * float[insar_conv3x3_flat_stat_rows(x, N, flip)][2][N]. insar_conv3x3_flat_ok() is the library's own
  * eligibility heuristic (enough tiles to fill the chip, W,H >= 30). */
 int insar_conv3x3_flat_ok(const InsarAct* x, int32_t N);
 int insar_conv3x3_flat_num_mtiles(const InsarAct* x);
