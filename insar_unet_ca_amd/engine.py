@@ -267,6 +267,7 @@ SPLIT_COEF = os.environ.get("INSAR_SPLIT_COEF", "0") == "1"
 POOL_FUSE = os.environ.get("INSAR_POOL_FUSE", "1") != "0"        # diagnostic: 0 routes the max-pool gradient with insar_maxpool2_bwd
 PREP_SIDE = os.environ.get("INSAR_PREP_SIDE", "1") != "0"         # diagnostic: 0 re-lays the weights out on the main stream
 OUTC_FUSE = os.environ.get("INSAR_OUTC_FUSE", "1") != "0"        # diagnostic: 0 materialises the gradient of outc's input
+WGRAD_GRID_CAP = int(os.environ.get("INSAR_WGRAD_GRID_CAP", "200"))    # 8-wave weight-gradient launches beside the dgrad chain: at most this many work-groups (0 = off)
 OUTC_WGRAD_FUSE = os.environ.get("INSAR_OUTC_WGRAD_FUSE", "1") != "0"   # diagnostic: 0 = outc's weight gradient in its own pass over y
 WGRAD_FILL_T = float(os.environ.get("INSAR_WGRAD_FILL_T", "0.5"))   # the same for the transposed convs' per-tap weight gradient
 WGRAD_FILL_ALONE = float(os.environ.get("INSAR_WGRAD_FILL_ALONE", "1.0"))   # ... and when it has the GPU to itself
@@ -717,6 +718,11 @@ def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
         # 9.26 ms/step). Alone on the GPU (single-stream runs, the per-kernel event pass of bench.py) it fills the chip.
         fill = _side_fill(ctx, WGRAD_FILL) if (ctx.side is not None and not (PROFILER is not None and PROFILER.alone)) else WGRAD_FILL_ALONE
         nsplit = _wgrad_nsplit(tiles, B * H * W // WG_BKP, 9 * cout * cin, tm, tn, ctx.esize, taps_per_wg=3, fill=fill)
+        if WGRAD_GRID_CAP and fill < 1.0 and tm * tn >= 128 * 128:
+            # deep layers (48 - 192 tiles): the cost model lands on 240 - 384 one-per-CU work-groups; beside the dgrad chain a
+            # grid that leaves CUs to the main stream does better (same-box sweep, tiles/s: no cap 2 110, <= 256: 2 117,
+            # <= 200: 2 126, <= 160: 2 082, <= 128: 2 054)
+            nsplit = min(nsplit, max(1, WGRAD_GRID_CAP // tiles))
         part = ctx.wgrad_part(nsplit * 9 * cout * cin)
         if PROFILER is not None:
             tag = "wgrad3_kernel<%s, %d, %d, %d>" % ("float" if ctx.code == _lib.F32 else "bf16_t", tm, tn,
