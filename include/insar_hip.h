@@ -278,6 +278,12 @@ typedef struct InsarBnSeBwd {
 } InsarBnSeBwd;
 int insar_bnse_bwd_coef(const InsarBnSeBwd* d, const float* red, int32_t rows, const float* scale,
                         const float* shift, float* ws, float* dconv_bias, int32_t training, void* stream);
+/* The same in ONE launch: the work-group that finishes stage 1 last (a ticket counter; the hand-off data written through
+ * to memory and read past the caches) runs stage 2. ticket: a zero-initialised 32-bit device word per call site (the
+ * kernel resets it); bitwise the results of insar_bnse_bwd_coef. Pays for units without an SE gate, whose stage 2 is small. */
+int insar_bnse_bwd_coef_fused(const InsarBnSeBwd* d, const float* red, int32_t rows, const float* scale,
+                              const float* shift, float* ws, float* dconv_bias, int32_t training, uint32_t* ticket,
+                              void* stream);
 int insar_bnrelu_bwd_apply(const InsarAct* dout, const InsarAct* y, const float* scale,
                            const float* shift, const float* mean, const float* invstd,
                            const float* gate, const float* coefB, const float* k1,

@@ -1157,14 +1157,24 @@ extern "C" int insar_se_excite(const InsarSeFwd* d, void* stream) {
 // stage 2 (thread per channel / per weight): dgamma, dbeta, k1, k2, dW1, dW2, conv-bias grad.
 // ws layout (floats): du[B][C] | dt[B][Cr] | tb[B][C] | tg[B][C]
 // ---------------------------------------------------------------------------------------------
+// Hand-off of stage-1 results to the work-group that runs stage 2 in the SAME launch (bnse_bwd_fused): written through to
+// memory and read past the non-coherent caches (agent-scope relaxed atomics = `sc1` stores / loads): no release / acquire
+// fence (a release fence writes back every dirty line of the XCD's L2 — the activations the step has just produced).
+template <bool COH> __device__ __forceinline__ void hand_st(float* p, float v) {
+  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+template <bool COH> __device__ __forceinline__ float hand_ld(const float* p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *p;
+}
+
 struct BnSeBwdArgs {
   InsarBnSeBwd d;
   const float* red; int rows; const float* scale; const float* shift;
   float* ws; float* dconv_bias; int training;
 };
 
-__global__ void __launch_bounds__(COEF_THREADS) bnse_bwd_stage1(BnSeBwdArgs a) {
-  extern __shared__ float sm[];
+template <bool COH>
+__device__ __forceinline__ void bnse_stage1_body(const BnSeBwdArgs& a, float* sm) {
   const InsarBnSeBwd& d = a.d;
   float* du_s = sm;              // [C]
   float* dt_s = sm + d.C;        // [Cr]
@@ -1184,7 +1194,7 @@ __global__ void __launch_bounds__(COEF_THREADS) bnse_bwd_stage1(BnSeBwdArgs a) {
       const float ds = a.scale[c] * q + a.shift[c] * p2;         // sum dout * z
       const float s = d.gate[(int64_t)n * d.C + c];
       const float du = ds * s * (1.f - s);
-      du_s[c] = du; du_g[c] = du;
+      du_s[c] = du; hand_st<COH>(du_g + c, du);
     }
     __syncthreads();
     // dt[j] = relu'(hid[j]) * sum_c du[c] * w2[c][j]: waves stride over the rows c of w2, lanes over j
@@ -1203,7 +1213,7 @@ __global__ void __launch_bounds__(COEF_THREADS) bnse_bwd_stage1(BnSeBwdArgs a) {
         float t = 0.f;
         for (int w = 0; w < nw; ++w) t += scratch[w * 64 + lane];
         const float dtv = d.hid[(int64_t)n * d.Cr + j] > 0.f ? t : 0.f;
-        dt_s[j] = dtv; dt_g[j] = dtv;
+        dt_s[j] = dtv; hand_st<COH>(dt_g + j, dtv);
       }
       __syncthreads();
     }
@@ -1225,14 +1235,20 @@ __global__ void __launch_bounds__(COEF_THREADS) bnse_bwd_stage1(BnSeBwdArgs a) {
       p5 = istd * (sy - mean * cnt);
       d.coefB[(int64_t)n * d.C + c] = cb;
     }
-    tb_g[c] = s * p2 + cb * cnt;
-    tg_g[c] = s * p4 + cb * p5;
+    hand_st<COH>(tb_g + c, s * p2 + cb * cnt);
+    hand_st<COH>(tg_g + c, s * p4 + cb * p5);
   }
 }
 
-__global__ void bnse_bwd_stage2(BnSeBwdArgs a) {
+__global__ void __launch_bounds__(COEF_THREADS) bnse_bwd_stage1(BnSeBwdArgs a) {
+  extern __shared__ float sm[];
+  bnse_stage1_body<false>(a, sm);
+}
+
+// element `tid` of stage 2 (a channel and / or an SE weight)
+template <bool COH>
+__device__ __forceinline__ void bnse_stage2_elem(const BnSeBwdArgs& a, int64_t tid) {
   const InsarBnSeBwd& d = a.d;
-  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const float* du_g = a.ws;
   const float* dt_g = a.ws + (int64_t)d.B * d.C;
   const float* tb_g = a.ws + (int64_t)d.B * (d.C + d.Cr);
@@ -1240,7 +1256,7 @@ __global__ void bnse_bwd_stage2(BnSeBwdArgs a) {
   if (tid < d.C) {
     const int c = (int)tid;
     float db = 0.f, dg = 0.f;
-    for (int n = 0; n < d.B; ++n) { db += tb_g[(int64_t)n * d.C + c]; dg += tg_g[(int64_t)n * d.C + c]; }
+    for (int n = 0; n < d.B; ++n) { db += hand_ld<COH>(tb_g + (int64_t)n * d.C + c); dg += hand_ld<COH>(tg_g + (int64_t)n * d.C + c); }
     const float invN = 1.f / ((float)d.B * (float)d.H * (float)d.W);
     d.k1[c] = a.training ? db * invN : 0.f;
     d.k2[c] = a.training ? dg * invN : 0.f;
@@ -1256,14 +1272,42 @@ __global__ void bnse_bwd_stage2(BnSeBwdArgs a) {
   if (tid < nw) {                       // dW2[c][j] = sum_n du[n][c] * hid[n][j]
     const int c = (int)(tid / d.Cr), j = (int)(tid - (int64_t)c * d.Cr);
     float acc = 0.f;
-    for (int n = 0; n < d.B; ++n) acc = fmaf(du_g[(int64_t)n * d.C + c], d.hid[(int64_t)n * d.Cr + j], acc);
+    for (int n = 0; n < d.B; ++n) acc = fmaf(hand_ld<COH>(du_g + (int64_t)n * d.C + c), d.hid[(int64_t)n * d.Cr + j], acc);
     if (d.accumulate) d.dw2[tid] += acc; else d.dw2[tid] = acc;
     // dW1[j][c] = sum_n dt[n][j] * sq[n][c]   (index tid2 = j*C + c)
     const int j1 = (int)(tid / d.C), c1 = (int)(tid - (int64_t)j1 * d.C);
     float acc1 = 0.f;
-    for (int n = 0; n < d.B; ++n) acc1 = fmaf(dt_g[(int64_t)n * d.Cr + j1], d.sq[(int64_t)n * d.C + c1], acc1);
+    for (int n = 0; n < d.B; ++n) acc1 = fmaf(hand_ld<COH>(dt_g + (int64_t)n * d.Cr + j1), d.sq[(int64_t)n * d.C + c1], acc1);
     if (d.accumulate) d.dw1[tid] += acc1; else d.dw1[tid] = acc1;
   }
+}
+
+__global__ void bnse_bwd_stage2(BnSeBwdArgs a) {
+  bnse_stage2_elem<false>(a, blockIdx.x * (int64_t)blockDim.x + threadIdx.x);
+}
+
+// Both stages in ONE launch, for units WITHOUT an SE gate (stage 2 is then C elements of 2 * B loads): every work-group runs
+// stage 1 for its image with the hand-off results written through to memory, drains its stores and draws a ticket; the
+// work-group that draws the last one runs stage 2, reading the hand-off data past the caches. One launch less on the
+// input-gradient chain per such unit. The ticket resets itself. Same arithmetic in the same order: bitwise equal.
+__global__ void __launch_bounds__(COEF_THREADS) bnse_bwd_fused(BnSeBwdArgs a, unsigned int* ticket) {
+  extern __shared__ float sm[];
+  __shared__ int s_last;
+  bnse_stage1_body<true>(a, sm);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's write-through stores have reached memory
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = prev == gridDim.x - 1;
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch starts from zero
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  const InsarBnSeBwd& d = a.d;
+  int64_t work = d.C;
+  if (d.use_se && (int64_t)d.C * d.Cr > work) work = (int64_t)d.C * d.Cr;
+  for (int64_t e = threadIdx.x; e < work; e += blockDim.x) bnse_stage2_elem<true>(a, e);
 }
 
 static int launch_bnse_coef(const char* who, const InsarBnSeBwd* d, const float* red, int32_t rows, const float* scale,
@@ -1292,6 +1336,24 @@ static int launch_bnse_coef(const char* who, const InsarBnSeBwd* d, const float*
 extern "C" int insar_bnse_bwd_coef(const InsarBnSeBwd* d, const float* red, int32_t rows, const float* scale,
                                    const float* shift, float* ws, float* dconv_bias, int32_t training, void* stream) {
   return launch_bnse_coef("insar_bnse_bwd_coef", d, red, rows, scale, shift, ws, dconv_bias, training, 3, stream);
+}
+
+// The two stages in one launch (see bnse_bwd_fused). ticket: one zero-initialised 32-bit word per call site, reset by the
+// kernel itself; calls that share a ticket must be ordered on one stream.
+extern "C" int insar_bnse_bwd_coef_fused(const InsarBnSeBwd* d, const float* red, int32_t rows, const float* scale,
+                                         const float* shift, float* ws, float* dconv_bias, int32_t training,
+                                         uint32_t* ticket, void* stream) {
+  if (!ticket) INSAR_FAIL(INSAR_E_ARG, "insar_bnse_bwd_coef_fused: null ticket");
+  if (!d || !red || !scale || !shift || !ws || !d->mean || !d->invstd || !d->dgamma || !d->dbeta || !d->k1 || !d->k2)
+    INSAR_FAIL(INSAR_E_ARG, "insar_bnse_bwd_coef_fused: null pointer");
+  if (d->use_se && (!d->pooled || !d->sq || !d->hid || !d->gate || !d->w1 || !d->w2 || !d->dw1 || !d->dw2 || !d->coefB))
+    INSAR_FAIL(INSAR_E_ARG, "insar_bnse_bwd_coef_fused: SE pointers missing");
+  if (d->C > 8192 || d->B < 1 || rows < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_bnse_bwd_coef_fused: bad shape");
+  BnSeBwdArgs a; a.d = *d; a.red = red; a.rows = rows; a.scale = scale; a.shift = shift; a.ws = ws; a.dconv_bias = dconv_bias; a.training = training;
+  size_t lds = (size_t)(3 * d->C + d->Cr + 1 + COEF_THREADS) * sizeof(float);
+  hipLaunchKernelGGL(bnse_bwd_fused, dim3(d->B), dim3(COEF_THREADS), lds, (hipStream_t)stream, a, (unsigned int*)ticket);
+  INSAR_CHECK_LAUNCH("insar_bnse_bwd_coef_fused");
+  return INSAR_OK;
 }
 
 // One stage of the above: 1 = per-image stage (SE backward, coefB, the per-image partial sums in ws), 2 = batch fold

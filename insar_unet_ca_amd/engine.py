@@ -268,6 +268,7 @@ POOL_FUSE = os.environ.get("INSAR_POOL_FUSE", "1") != "0"        # diagnostic: 0
 PREP_SIDE = os.environ.get("INSAR_PREP_SIDE", "1") != "0"         # diagnostic: 0 re-lays the weights out on the main stream
 OUTC_FUSE = os.environ.get("INSAR_OUTC_FUSE", "1") != "0"        # diagnostic: 0 materialises the gradient of outc's input
 WGRAD_GRID_CAP = int(os.environ.get("INSAR_WGRAD_GRID_CAP", "200"))    # 8-wave weight-gradient launches beside the dgrad chain: at most this many work-groups (0 = off)
+COEF_FUSE = os.environ.get("INSAR_COEF_FUSE", "1") != "0"        # diagnostic: 0 = two launches for the coefficient stages of every unit
 OUTC_WGRAD_FUSE = os.environ.get("INSAR_OUTC_WGRAD_FUSE", "1") != "0"   # diagnostic: 0 = outc's weight gradient in its own pass over y
 WGRAD_FILL_T = float(os.environ.get("INSAR_WGRAD_FILL_T", "0.5"))   # the same for the transposed convs' per-tap weight gradient
 WGRAD_FILL_ALONE = float(os.environ.get("INSAR_WGRAD_FILL_ALONE", "1.0"))   # ... and when it has the GPU to itself
@@ -510,6 +511,7 @@ class ConvBN:
         self.mean, self.invstd = ctx.f32(self.cout), ctx.f32(self.cout)
         self.k12 = ctx.f32(2, self.cout)                  # one buffer: SyncBN all-reduces both coefficient vectors at once
         self.k1, self.k2 = self.k12[0], self.k12[1]
+        self._ticket = None                               # last-arriver counter of the single-launch coefficient stages
         self.sync_sums = None                             # [2][C] batch sums of this replica (SyncBN only)
         self.sync = None
         self.red_rpp = _rows_per_part(B, H)
@@ -587,6 +589,16 @@ class ConvBN:
         call("insar_bn_relu_apply", self.y.ref, ptr(self.scale), ptr(self.shift), ptr(gate), dst.ref, 1,
              _lib.stream_ptr())
 
+    def _coef(self, coef_args, s, se) -> None:
+        """Both coefficient stages: ONE launch for a unit without an SE gate (stage 2 by the work-group that finishes stage 1
+        last; COEF_FUSE), else two (with a gate stage 2 carries the SE weight gradients, too much for one work-group)."""
+        if COEF_FUSE and se is None:
+            if self._ticket is None:
+                self._ticket = torch.zeros(1, dtype=torch.int32, device=self.ctx.device)
+            call("insar_bnse_bwd_coef_fused", *coef_args, ptr(self._ticket), s)
+        else:
+            call("insar_bnse_bwd_coef", *coef_args, s)
+
     def _sync_k(self) -> None:
         """SyncBN backward: k1 = mean(g*mask), k2 = mean(g*mask*xhat) over the GLOBAL batch = the mean over the replicas of
         their local means (equal local batch sizes)."""
@@ -651,19 +663,19 @@ class ConvBN:
                  self.dy.ref, 1, s)
             stage2 = lambda: call("insar_bnse_bwd_coef_stage", *coef_args, 2, _lib.stream_ptr())
         elif outc_grad is not None:
-            call("insar_bnse_bwd_coef", *coef_args, s)
+            self._coef(coef_args, s, se)
             self._sync_k()
             call("insar_bnrelu_bwd_apply_outc", ptr(dl), ptr(wout), K, self.y.ref, ptr(self.scale), ptr(self.shift),
                  ptr(self.mean), ptr(self.invstd), ptr(se.gate) if se else 0, ptr(se.coefB) if se else 0, ptr(self.k1),
                  ptr(self.k2), self.dy.ref, 1, s)
         elif pool_grad is not None:
-            call("insar_bnse_bwd_coef", *coef_args, s)
+            self._coef(coef_args, s, se)
             self._sync_k()
             call("insar_bnrelu_bwd_apply_pool", dout.ref, dpool.ref, ptr(parg), self.y.ref, ptr(self.scale), ptr(self.shift),
                  ptr(self.mean), ptr(self.invstd), ptr(se.gate) if se else 0, ptr(se.coefB) if se else 0, ptr(self.k1),
                  ptr(self.k2), self.dy.ref, 1, s)
         else:
-            call("insar_bnse_bwd_coef", *coef_args, s)
+            self._coef(coef_args, s, se)
             self._sync_k()
             call("insar_bnrelu_bwd_apply", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.mean),
                  ptr(self.invstd), ptr(se.gate) if se else 0, ptr(se.coefB) if se else 0, ptr(self.k1), ptr(self.k2),

@@ -117,7 +117,8 @@ def test_plan_launch_sequence(mocked_abi):
     assert c["insar_bn_relu_apply_pool_arg"] == 4 and c.get("insar_maxpool2_bwd", 0) == 0
     assert c["insar_bnrelu_bwd_reduce_pool"] == 4 and c["insar_bnrelu_bwd_apply_pool"] == 4
     # the unit that feeds outc recomputes its incoming gradient from dlogits; outc only produces its parameter gradients
-    assert c["insar_bnse_bwd_coef"] == 18 and c["insar_bnrelu_bwd_apply"] == 13 and c["insar_bnrelu_bwd_apply_outc"] == 1
+    # coefficient stages: one launch for the nine units without an SE gate, two for the nine with one
+    assert c["insar_bnse_bwd_coef"] == 9 and c["insar_bnse_bwd_coef_fused"] == 9 and c["insar_bnrelu_bwd_apply"] == 13 and c["insar_bnrelu_bwd_apply_outc"] == 1
     # ... and those come out of the same reduce pass (one read of y), folded by a column sum: no pass of their own
     assert c["insar_bnrelu_bwd_reduce_outc"] == 1 and c.get("insar_conv1x1_out_wgrad_y", 0) == 0 and c.get("insar_conv1x1_out_bwd", 0) == 0
     # ... and in forward its BN/ReLU/gate pass writes the logits itself (no 64-channel output tensor, no separate outc launch)

@@ -1130,6 +1130,38 @@ def test_outc_weight_gradient_from_the_reduce_pass(dev, dtype, size, monkeypatch
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_single_launch_coefficient_stages_are_bitwise_the_two_launches(dev, dtype, monkeypatch):
+    """insar_bnse_bwd_coef_fused (units without an SE gate: stage 2 by the work-group that draws the last ticket after
+    stage 1; hand-off data written through to memory and read past the caches) against insar_bnse_bwd_coef's two
+    launches: every gradient bit for bit, 30 backward passes in a row through the same ticket words (they must reset
+    themselves)."""
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd import engine
+    from insar_unet_ca_amd.data import make_batch
+    x, y = make_batch(4, 16, 64)
+    x, y = x.to(dev), y.to(dev)
+    ref = None
+    for fuse, reps in ((False, 1), (True, 30)):
+        monkeypatch.setattr(engine, "COEF_FUSE", fuse)
+        torch.manual_seed(5)
+        net = iu.UNet(2, 2, True, compute_dtype=dtype).to(dev).train()
+        crit = iu.DiceCELoss(ignore_index=255)
+        names = [n for n, _ in net.named_parameters()]
+        for rep in range(reps):
+            for p in net.parameters():
+                p.grad = None
+            loss = crit(net(x), y)
+            loss.backward()
+            torch.cuda.synchronize()
+            g = [p.grad.clone() for p in net.parameters()]
+            if ref is None:
+                ref = g
+            else:
+                bad = [n for n, a, b in zip(names, g, ref) if not torch.equal(a, b)]
+                assert not bad, (rep, bad[:6])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_pool_gradient_inside_bn_backward_is_bitwise_maxpool2_bwd(dev, dtype, monkeypatch):
     """Arg-max map written by the forward apply+pool pass, pooled gradient added to the skip gradient on the fly in the
     encoder blocks' BatchNorm-backward passes: same gradient bits as insar_maxpool2_bwd accumulating into the skip
