@@ -156,6 +156,8 @@ def main() -> int:
         opt.step()
         return loss
 
+    if os.environ.get("INSAR_MAIN_PRIORITY"):      # diagnostic: the whole step on a stream of this HIP priority
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(os.environ["INSAR_MAIN_PRIORITY"])))
     use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
     if use_graph and world > 1:
         print("error: --graph on is not available under data parallelism", file=sys.stderr)

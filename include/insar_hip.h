@@ -54,6 +54,12 @@ typedef struct InsarAct {
 int insar_version(void);
 const char* insar_last_error(void);
 
+/* Kernel-variant selectors for same-process A/B measurements (tools/, bench.py --tune): named integer knobs read by
+ * the launchers at launch time. Every value of every knob selects between kernels that the parity tests hold to
+ * the same tolerances; unknown names return INSAR_E_ARG. Not part of the reference's surface (it has no kernels). */
+int insar_tune_set(const char* name, int32_t value);
+int insar_tune_get(const char* name);   /* value, or INSAR_E_ARG */
+
 /* ---- layout conversion at the nn.Module boundary (forward(x:[B,C,H,W]), :127) ------------ */
 /* NCHW contiguous fp32 -> padded NHWC slice (cast to dst.dtype). */
 int insar_pack_nchw(const float* src, const InsarAct* dst, void* stream);

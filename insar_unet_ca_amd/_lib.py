@@ -166,6 +166,8 @@ _SIGNATURES = {
     "insar_dropout": [_AP, _AP, _P, C.c_uint64, _P, _F, _I, _P],
     "insar_bilinear_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "insar_bilinear_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "insar_tune_set": [C.c_char_p, _I],
+    "insar_tune_get": [C.c_char_p],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["insar_version", "insar_last_error"])
 
@@ -197,10 +199,14 @@ def load():
     if lib.insar_version() != ABI_VERSION:
         raise InsarError(f"libinsar_hip.so ABI {lib.insar_version()} != expected {ABI_VERSION}")
     _lib = lib
+    for item in filter(None, os.environ.get("INSAR_TUNE", "").split(",")):
+        k, _, v = item.partition("=")
+        if lib.insar_tune_set(k.strip().encode(), int(v or 1)) != 0:
+            raise InsarError(f"INSAR_TUNE: unknown knob {k!r}")
     return lib
 
 
-_COUNT_ONLY = {"insar_igemm_num_mtiles", "insar_igemm_tile_rows", "insar_igemm_tile_cols", "insar_igemm_tile_cols_dt", "insar_wgrad_tile", "insar_wgrad_tile_pair", "insar_wgrad_conv3_tile", "insar_conv3x3_flat_ok", "insar_conv3x3_flat_num_mtiles", "insar_conv3x3_flat_stat_rows", "insar_conv3x3_c64_ok", "insar_conv3x3_c64_rows", "insar_conv3x3_c64_geometry", "insar_conv3x3_small_wgrad_blocks", "insar_conv3x3_small_fwd_rows", "insar_conv1x1_out_bwd_blocks",
+_COUNT_ONLY = {"insar_tune_get", "insar_igemm_num_mtiles", "insar_igemm_tile_rows", "insar_igemm_tile_cols", "insar_igemm_tile_cols_dt", "insar_wgrad_tile", "insar_wgrad_tile_pair", "insar_wgrad_conv3_tile", "insar_conv3x3_flat_ok", "insar_conv3x3_flat_num_mtiles", "insar_conv3x3_flat_stat_rows", "insar_conv3x3_c64_ok", "insar_conv3x3_c64_rows", "insar_conv3x3_c64_geometry", "insar_conv3x3_small_wgrad_blocks", "insar_conv3x3_small_fwd_rows", "insar_conv1x1_out_bwd_blocks",
                "insar_ce_blocks", "insar_conv7x7s2_fwd_rows", "insar_conv7x7s2_wgrad_blocks"}
 
 
@@ -238,3 +244,15 @@ def dtype_code(dt: torch.dtype) -> int:
 
 def ptr(t) -> int:
     return 0 if t is None else t.data_ptr()
+
+
+def tune(name: str, value: int = None) -> int:
+    """Set (or read) a kernel-variant knob of the library (include/insar_hip.h: insar_tune_set). INSAR_TUNE=name=v,name=v
+    in the environment sets knobs when the library is first used (A/B runs of bench.py)."""
+    if value is None:
+        v = call("insar_tune_get", name.encode())
+        if v == -1005:
+            raise InsarError(f"unknown tuning knob {name!r}")
+        return v
+    call("insar_tune_set", name.encode(), int(value))
+    return int(value)

@@ -15,6 +15,31 @@ void insar_set_error(const char* fmt, ...) {
 extern "C" const char* insar_last_error(void) { return g_err; }
 extern "C" int insar_version(void) { return INSAR_ABI_VERSION; }
 
+// ---- kernel-variant knobs ------------------------------------------------------------------------
+#include <atomic>
+static const char* const g_knob_names[KNOB_COUNT] = {
+    "wgrad3_m32",     // row-of-taps weight gradient, 128 x 128 bf16 tiles: 1 = v_mfma_f32_32x32x16_bf16 fragments
+};
+static std::atomic<int> g_knobs[KNOB_COUNT] = {};     // defaults: 0
+int insar_knob(int id) { return g_knobs[id].load(std::memory_order_relaxed); }
+static int knob_index(const char* name) {
+  if (!name) return -1;
+  for (int i = 0; i < KNOB_COUNT; ++i)
+    if (!strcmp(name, g_knob_names[i])) return i;
+  return -1;
+}
+extern "C" int insar_tune_set(const char* name, int32_t value) {
+  const int i = knob_index(name);
+  if (i < 0) INSAR_FAIL(INSAR_E_ARG, "insar_tune_set: unknown knob '%s'", name ? name : "(null)");
+  g_knobs[i].store(value, std::memory_order_relaxed);
+  return INSAR_OK;
+}
+extern "C" int insar_tune_get(const char* name) {
+  const int i = knob_index(name);
+  if (i < 0) INSAR_FAIL(INSAR_E_ARG, "insar_tune_get: unknown knob '%s'", name ? name : "(null)");
+  return g_knobs[i].load(std::memory_order_relaxed);
+}
+
 int insar_check_act(const InsarAct* a, const char* who, const char* what) {
   if (!a || !a->ptr) INSAR_FAIL(INSAR_E_ARG, "%s: %s is null", who, what);
   if (a->dtype != INSAR_F32 && a->dtype != INSAR_BF16) INSAR_FAIL(INSAR_E_DTYPE, "%s: %s has dtype %d", who, what, a->dtype);

@@ -31,9 +31,16 @@ struct Wgrad3Args {
   int mtc, ntc;
 };
 
-template <int RB>
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+// XOR of the 16-byte chunk index of a staged row (DMA source side and read side alike). MF = 16: the two lane groups
+// of a 32-lane half read DIFFERENT pixel rows (0-3 and 12-15 of their 16) of the same 32-byte channel block. MF = 32
+// (v_mfma_f32_32x32x16_bf16 fragments, 256-byte rows only): they read the SAME four pixel rows of two adjacent channel
+// blocks, so four consecutive rows must land in four different 64-byte segments of the 256-byte bank row.
+template <int RB, int MF = 16>
 __device__ __forceinline__ int w3_swz(int row) {
-  if constexpr (RB == 256) return (row & 7) << 1;
+  if constexpr (MF == 32) return ((row & 3) << 2) | (((row >> 2) & 1) << 1);
+  else if constexpr (RB == 256) return (row & 7) << 1;
   else return ((row >> 1) & 3) << 1;
 }
 
@@ -54,9 +61,10 @@ struct Wgrad3Cfg {
   static_assert(YCHUNKS % THREADS == 0, "dY stage must be whole block-wide DMA instructions");
 };
 
-template <typename T, int TM, int TN, int NW>
+template <typename T, int TM, int TN, int NW, int MF = 16>
 __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad3_kernel(Wgrad3Args a) {
   using Cfg = Wgrad3Cfg<T, TM, TN, NW>;
+  static_assert(MF == 16 || (MF == 32 && sizeof(T) == 2 && TM == 128 && TN == 128 && NW == 8), "32x32x16 fragments: 128 x 128 bf16 tiles");
   constexpr int THREADS = Cfg::THREADS, ES = Cfg::ES;
   constexpr int MTW = Cfg::MTW, NTW = Cfg::NTW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -85,7 +93,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad3_kernel(Wgra
     const int q = i * THREADS + tid;
     const int sub = q / (W3_XR * Cfg::CPRX), row = (q / Cfg::CPRX) % W3_XR, pos = q % Cfg::CPRX;
     xrow_i[i] = row;
-    xoff_i[i] = sub * Cfg::RBX + (pos ^ w3_swz<Cfg::RBX>(row)) * 16;
+    xoff_i[i] = sub * Cfg::RBX + (pos ^ w3_swz<Cfg::RBX, MF>(row)) * 16;
     xok_i[i] = q < Cfg::XCHUNKS && row < W3_BKP + 2 * a.rpk;
   }
   int yrow_i[Cfg::NY], yoff_i[Cfg::NY];
@@ -94,7 +102,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad3_kernel(Wgra
     const int q = i * THREADS + tid;
     const int sub = q / (W3_BKP * Cfg::CPRY), row = (q / Cfg::CPRY) % W3_BKP, pos = q % Cfg::CPRY;
     yrow_i[i] = row + 2 * (row >> a.lw);              // padded pixel offset of dY row `row` (halo pixels skipped)
-    yoff_i[i] = sub * Cfg::RBY + (pos ^ w3_swz<Cfg::RBY>(row)) * 16;
+    yoff_i[i] = sub * Cfg::RBY + (pos ^ w3_swz<Cfg::RBY, MF>(row)) * 16;
   }
   const long long xpitch = (long long)a.Cx * ES, ypitch = (long long)a.Cdy * ES;
   // A K step is 64 interior pixels: a piece of one image row (W >= 64) or 64/W whole image rows (W = 16, 32). In the
@@ -132,13 +140,22 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad3_kernel(Wgra
       lds_dma16_untracked(ybase + (p0 + yrow_i[i]) * ypitch + yoff_i[i], ly + i * (THREADS * 16));
   };
 
-  f32x4_t acc[3][MTW][NTW];
+  // MF = 16: 16x16 accumulators [tap][MTW][NTW]; MF = 32: the wave's 64 (ci) x 32 (co) as two 32x32 accumulators per tap
+  constexpr int A16 = MF == 16 ? 3 : 1, A32 = MF == 32 ? 3 : 1;
+  f32x4_t acc[A16][MTW][NTW];
+  f32x16_t acc32[A32][2];
 #pragma unroll
-  for (int t3 = 0; t3 < 3; ++t3)
+  for (int t3 = 0; t3 < A16; ++t3)
 #pragma unroll
     for (int i = 0; i < MTW; ++i)
 #pragma unroll
       for (int j = 0; j < NTW; ++j) acc[t3][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t3 = 0; t3 < A32; ++t3)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc32[t3][i][e] = 0.f;
 
   const int wm = wave & 1, wn = wave >> 1;
   const int r16 = lane & 15, kq = lane >> 4;
@@ -151,7 +168,44 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad3_kernel(Wgra
       if (ks + 1 < ks1) stage(buf ^ 1, next_pixel());
       const char* sX = smem + buf * Cfg::STAGE;
       const char* sY = sX + Cfg::X_STAGE;
-      if constexpr (ES == 2) {
+      if constexpr (ES == 2 && MF == 32) {
+        // lane = 16*g + i: channel block cb = g & 1 (16 channels), k half hq = g >> 1 (8 pixels) of a 16-pixel MFMA step;
+        // a transposing read hands lane i channel i of the four pixel rows its 16-lane group addresses (row q = i >> 2)
+        const int cb = kq & 1, hq = kq >> 1;
+  #pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          bf16x8_t yf;
+  #pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int row = s * 16 + hq * 8 + h * 4 + (r16 >> 2);
+            const int colb = (wn * 32 + cb * 16 + (r16 & 3) * 4) * 2;
+            const int pc = (colb >> 4) ^ w3_swz<Cfg::RBY, MF>(row);
+            const char* p = sY + row * Cfg::RBY + pc * 16 + (colb & 15);
+            s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+            yf[4 * h + 0] = v[0]; yf[4 * h + 1] = v[1]; yf[4 * h + 2] = v[2]; yf[4 * h + 3] = v[3];
+          }
+  #pragma unroll
+          for (int t3 = 0; t3 < 3; ++t3) {
+            bf16x8_t xf[2];
+  #pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int k = s * 16 + hq * 8 + h * 4 + (r16 >> 2);
+              const int row = k + 2 * (k >> a.lw) + t3;
+  #pragma unroll
+              for (int mt = 0; mt < 2; ++mt) {
+                const int colb = (wm * 64 + mt * 32 + cb * 16 + (r16 & 3) * 4) * 2;
+                const int pc = (colb >> 4) ^ w3_swz<Cfg::RBX, MF>(row);
+                const char* p = sX + row * Cfg::RBX + pc * 16 + (colb & 15);
+                s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+                xf[mt][4 * h + 0] = v[0]; xf[mt][4 * h + 1] = v[1]; xf[mt][4 * h + 2] = v[2]; xf[mt][4 * h + 3] = v[3];
+              }
+            }
+  #pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+              acc32[t3][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[mt], yf, acc32[t3][mt], 0, 0, 0);
+          }
+        }
+      } else if constexpr (ES == 2) {
   #pragma unroll
         for (int s = 0; s < 2; ++s) {
           bf16x8_t yf[NTW];
@@ -232,6 +286,23 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad3_kernel(Wgra
     }
   }
 
+  if constexpr (MF == 32) {
+    // C layout of a 32x32 accumulator: col (co) = lane & 31, row (ci) = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+#pragma unroll
+    for (int t3 = 0; t3 < 3; ++t3) {
+      float* out = a.part + ((long long)split * 9 + ty * 3 + t3) * a.Cout * a.Cin;
+      const int co = ni * TN + wn * 32 + (lane & 31);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int ci = mi * TM + wm * 64 + mt * 32 + 8 * b + 4 * (lane >> 5);
+          const f32x16_t c = acc32[t3][mt];
+          *(f32x4_t*)(out + (long long)co * a.Cin + ci) = (f32x4_t){c[4 * b], c[4 * b + 1], c[4 * b + 2], c[4 * b + 3]};
+        }
+    }
+    return;
+  }
   // C layout: row (ci) = kq*4 + reg, col (co) = r16  ->  16-byte stores into [co][ci]
 #pragma unroll
   for (int t3 = 0; t3 < 3; ++t3) {
@@ -247,18 +318,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad3_kernel(Wgra
   }
 }
 
-template <typename T, int TM, int TN, int NW>
+template <typename T, int TM, int TN, int NW, int MF = 16>
 static int launch_wgrad3(Wgrad3Args& a, hipStream_t s) {
   using Cfg = Wgrad3Cfg<T, TM, TN, NW>;
   static std::atomic<uint64_t> attr_mask{0};     // per-device, see common.h
   {
-    hipError_t e = insar_set_lds_once(attr_mask, (const void*)wgrad3_kernel<T, TM, TN, NW>, Cfg::LDS_BYTES);
+    hipError_t e = insar_set_lds_once(attr_mask, (const void*)wgrad3_kernel<T, TM, TN, NW, MF>, Cfg::LDS_BYTES);
     if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_wgrad_conv3: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   a.mtc = a.Cin / TM; a.ntc = a.Cout / TN;
   const long long grid = (long long)a.nsplit * 3 * a.mtc * a.ntc;
   if (grid > 0x7fffffffLL) INSAR_FAIL(INSAR_E_SHAPE, "insar_wgrad_conv3: grid too large");
-  hipLaunchKernelGGL((wgrad3_kernel<T, TM, TN, NW>), dim3((unsigned)grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((wgrad3_kernel<T, TM, TN, NW, MF>), dim3((unsigned)grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, a);
   INSAR_CHECK_LAUNCH("insar_wgrad_conv3");
   return INSAR_OK;
 }
@@ -308,7 +379,8 @@ extern "C" int insar_wgrad_conv3(const InsarAct* x, const InsarAct* dy, float* p
     if (tm == 128 && tn == 128) return launch_wgrad3<float, 128, 128, 8>(a, s);
     return launch_wgrad3<float, 64, 64, 4>(a, s);
   }
-  if (tm == 128 && tn == 128) return launch_wgrad3<bf16_t, 128, 128, 8>(a, s);
+  if (tm == 128 && tn == 128)
+    return insar_knob(KNOB_WGRAD3_M32) ? launch_wgrad3<bf16_t, 128, 128, 8, 32>(a, s) : launch_wgrad3<bf16_t, 128, 128, 8>(a, s);
   if (tm == 128) return launch_wgrad3<bf16_t, 128, 64, 4>(a, s);
   if (tn == 128) return launch_wgrad3<bf16_t, 64, 128, 4>(a, s);
   return launch_wgrad3<bf16_t, 64, 64, 4>(a, s);

@@ -63,7 +63,8 @@ class Ctx:
         # Weight gradients (wgrad GEMM + slab folds) depend on nothing but a layer's input and its dy, and
         # nothing in backward depends on them: they go to a second HIP stream so that they overlap the
         # HBM-bound BN/ReLU backward passes and the next dgrad on the main stream. INSAR_SIDE_STREAM=0 disables.
-        self.side = (torch.cuda.Stream(device=device)
+        # INSAR_SIDE_PRIORITY: HIP stream priority of the side stream (lower number = higher priority; diagnostic)
+        self.side = (torch.cuda.Stream(device=device, priority=int(os.environ.get("INSAR_SIDE_PRIORITY", "0")))
                      if device.type == "cuda" and os.environ.get("INSAR_SIDE_STREAM", "1") != "0" else None)
         self._side_busy = False
         self._wgrad_part: Optional[torch.Tensor] = None

@@ -25,7 +25,8 @@ class GraphedTrainStep:
     THIS step; reading it with .item() synchronises, as in the reference's loop :348).
 
     x, y fix the batch geometry. The model must be in training mode and stay there; parameters must not be re-assigned
-    (load_state_dict copies in place and is fine). `.grad` of every parameter is the gradient of the last step."""
+    (model.load_state_dict copies in place and is fine; so is optimizer.load_state_dict, which restores into the
+    existing state tensors — if it ever has to re-allocate them the next replay raises instead of updating freed memory). `.grad` of every parameter is the gradient of the last step."""
 
     def __init__(self, model: torch.nn.Module, criterion, optimizer, x: torch.Tensor, y: torch.Tensor, warmup: int = 3):
         if not x.is_cuda:
@@ -57,6 +58,7 @@ class GraphedTrainStep:
         optimizer._dev_pending -= 1         # the capture enqueued nothing: that optimizer.step() did not happen
         # the capture itself executed nothing: parameters, optimizer state and BatchNorm buffers are those after warm-up
         self.replays = 0
+        self._opt_generation = getattr(optimizer, "generation", 0)
 
     def _eager_step(self) -> torch.Tensor:
         self.optimizer.zero_grad(set_to_none=True)
@@ -70,6 +72,11 @@ class GraphedTrainStep:
             self.x.copy_(x, non_blocking=True)
         if y is not None:
             self.y.copy_(y, non_blocking=True)
+        if getattr(self.optimizer, "generation", 0) != self._opt_generation:
+            # the kernel nodes hold the addresses of the moment tensors and of the device-side step state as they were at
+            # capture time; a load that re-allocated them would make the replay update freed memory
+            raise _lib.InsarError("GraphedTrainStep: the optimizer's state was re-allocated after the capture "
+                                  "(optimizer.load_state_dict with new shapes / first-time state); build a new GraphedTrainStep")
         self.graph.replay()
         self.optimizer._dev_pending += 1
         self.replays += 1

@@ -408,6 +408,8 @@ class _UNetFn(torch.autograd.Function):
             # hot path (the reference never asks for it: images come from the loader). Say so instead of returning None.
             raise _lib.InsarError("UNet: the gradient with respect to the input tensor is not provided by the HIP path; "
                                   "pass the images with requires_grad=False")
+        if hooks and hooks.get("before_forward"):
+            hooks["before_forward"](plan)          # DataParallel: parameter all-gathers still in flight
         logits = plan.forward(x, training)
         ctx.plan, ctx.hooks = plan, hooks
         ctx.lease = _Lease(plan) if track else None

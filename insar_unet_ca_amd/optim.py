@@ -23,6 +23,7 @@ class Adam(torch.optim.Adam):
         self._dev_state = None     # float[4] on the device: step count + bias corrections (enable_device_step)
         self._dev_pending = 0      # steps taken on the device that state['step'] has not been told about yet
         self._fast = None          # (params, grads, step tensors, table, chunks, nchunks) of the last full step
+        self.generation = 0        # bumped whenever optimizer state had to be re-allocated (see load_state_dict)
 
     # ---- device-side step count (hipGraph capture) ---------------------------------------------------------
     def enable_device_step(self) -> None:
@@ -60,13 +61,37 @@ class Adam(torch.optim.Adam):
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
-        super().load_state_dict(state_dict)          # replaces the state tensors: cached pointer tables are stale
-        self._fast = None
-        self._tables.clear()
+        """Restores IN PLACE wherever the optimizer already holds state of the same shape: the moment tensors, the step
+        counters and the device-side step state keep their addresses, so cached pointer tables and a captured hipGraph
+        (graph.GraphedTrainStep bakes those addresses into its kernel nodes) stay valid and see the restored values.
+        State that has to be re-allocated (first load, changed shapes) bumps `generation`, which GraphedTrainStep checks."""
+        self._sync_host_steps()
+        old = {p: dict(st) for p, st in self.state.items()}
+        super().load_state_dict(state_dict)          # builds fresh state tensors
+        in_place = True
+        for p, st in self.state.items():
+            prev = old.get(p)
+            for k in ("exp_avg", "exp_avg_sq", "step"):
+                new = st.get(k)
+                keep = prev.get(k) if prev else None
+                if (torch.is_tensor(new) and torch.is_tensor(keep) and keep.shape == new.shape and keep.dtype == new.dtype
+                        and keep.device == new.device):
+                    keep.copy_(new)
+                    st[k] = keep
+                elif new is not None:
+                    in_place = False
+        if set(old) - set(self.state):
+            in_place = False
+        if not in_place:
+            self._fast = None
+            self._tables.clear()
+            self.generation += 1
         if self._dev_state is not None:
             self._dev_pending = 0
-            self._dev_state = None
-            self.enable_device_step()
+            keep, self._dev_state = self._dev_state, None
+            self.enable_device_step()                # validates the loaded step counts, builds the new values
+            keep.copy_(self._dev_state)              # ... which go into the tensor a captured graph already points at
+            self._dev_state = keep
 
     def _table(self, key, tensors):
         hit = self._tables.get(key)

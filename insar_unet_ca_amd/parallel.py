@@ -100,10 +100,12 @@ def bucket_bounds(sizes: List[int], min_elems: int) -> List[Tuple[int, int]]:
 
 
 class ShardedBuckets:
-    """This rank's 1/world slice of every bucket: the master copy of its parameters (`p`), the averaged gradients
-    (`g`) and the Adam moments (`m`, `v`). Bucket b covers flat[begin_b:end_b]; rank r owns
-    flat[begin_b + r*n_b : begin_b + (r+1)*n_b], n_b = (end_b - begin_b) / world (engine.GROUP_ALIGN makes every
-    bucket divisible into 16-byte aligned shards for world <= 16)."""
+    """This rank's 1/world slice of every bucket: its parameters (`p`: a VIEW of the flat parameter buffer, so whatever
+    changes the parameters in place — `load_state_dict` on resume, a manual re-initialisation — is what the next
+    optimizer step starts from, and the all-gather runs in place), the averaged gradients (`g`) and the Adam moments
+    (`m`, `v`). Bucket b covers flat[begin_b:end_b]; rank r owns flat[begin_b + r*n_b : begin_b + (r+1)*n_b],
+    n_b = (end_b - begin_b) / world (engine.GROUP_ALIGN makes every bucket divisible into 16-byte aligned shards for
+    world <= 16)."""
 
     def __init__(self, flat_p: torch.Tensor, bounds: List[Tuple[int, int]], world: int, rank: int):
         self.bounds, self.world, self.rank = bounds, world, rank
@@ -113,7 +115,7 @@ class ShardedBuckets:
                 raise ValueError(f"bucket of {e - b} elements does not split into {world} 16-byte aligned shards")
             n = (e - b) // world
             own = flat_p[b + rank * n: b + (rank + 1) * n]
-            self.p.append(own.clone())
+            self.p.append(own)
             self.g.append(torch.zeros_like(own))
             self.m.append(torch.zeros_like(own))
             self.v.append(torch.zeros_like(own))
@@ -152,6 +154,7 @@ class DataParallel(torch.nn.Module):
         self._bucket = 0
         self.sharded: Optional[ShardedBuckets] = None
         self.flat_p: Optional[torch.Tensor] = None
+        self._gathers: List = []
         if shard_optimizer:
             self._flatten_parameters()
         module._hooks["on_begin"] = self._on_begin
@@ -159,13 +162,19 @@ class DataParallel(torch.nn.Module):
         module._hooks["on_done"] = self._on_done
         if shard_optimizer:
             module._hooks["grad_mode"] = "none"
+            module._hooks["before_forward"] = self._params_ready
         if sync_bn:
             # synchronised BatchNorm (U-Net-CA plan): global-batch statistics, i.e. the reference's single-device batch
             # semantics under data parallelism, for two tiny all-reduces per BatchNorm layer and step
             module._hooks["sync_bn"] = (process_group, self.world)
 
     def forward(self, *args, **kwargs):
+        self._params_ready()
         return self.module(*args, **kwargs)
+
+    def state_dict(self, *args, **kwargs):
+        self._params_ready()
+        return super().state_dict(*args, **kwargs)
 
     # ---- sharded-optimizer layout ---------------------------------------------------------------------
     def _flatten_parameters(self) -> None:
@@ -190,14 +199,29 @@ class DataParallel(torch.nn.Module):
         self.flat_params = params
         self.sharded = ShardedBuckets(flat, bucket_bounds(sizes, self.min_elems), self.world, self.rank)
 
-    def gather_parameters(self) -> None:
-        """All-gather the updated shards into the flat parameter buffer (after ShardedAdam's kernel)."""
-        works = []
-        for (b, e), own in zip(self.sharded.bounds, self.sharded.p):
-            works.append(dist.all_gather_into_tensor(self.flat_p[b:e], own, group=self.pg, async_op=True))
-        for w in works:
-            w.wait()
+    def gather_parameters(self, wait: bool = False) -> None:
+        """All-gather the updated shards into the flat parameter buffer (after ShardedAdam's kernel), in place: every
+        rank's shard already sits at its slot of the bucket. The buckets are issued in the order the NEXT forward pass needs
+        them (the flat layout is backward-completion order, so the last bucket holds the first encoder levels) and nothing
+        waits here: `_params_ready` (run by the module's forward before its first launch, or by `wait=True`) makes the
+        compute streams wait, so the collectives overlap whatever the training loop does between optimizer.step() and the
+        next forward (zero_grad, the input copy, logging)."""
+        nccl = self.reducer.backend == "nccl"
+        for (b, e), own in reversed(list(zip(self.sharded.bounds, self.sharded.p))):
+            src = own if nccl else own.clone()        # gloo copies the input into the output slot: keep them distinct
+            self._gathers.append(dist.all_gather_into_tensor(self.flat_p[b:e], src, group=self.pg, async_op=True))
         torch._C._increment_version(self.flat_params)      # cached GEMM-layout copies of the weights are now stale
+        if wait:
+            self._params_ready()
+
+    def params_ready(self) -> None:
+        """Order the current stream after the parameter all-gathers of the last ShardedAdam.step(defer_gather=True)."""
+        self._params_ready()
+
+    def _params_ready(self, plan=None) -> None:
+        for w in self._gathers:
+            w.wait()                 # nccl: the current stream waits for the collective; no host sync
+        self._gathers.clear()
 
     @torch.no_grad()
     def sync_buffers(self) -> None:
@@ -279,10 +303,14 @@ class ShardedAdam:
     CPU (gloo) tests of the exchange logic; the product path leaves it None."""
 
     def __init__(self, dp: DataParallel, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 kernel: Optional[Callable] = None):
+                 kernel: Optional[Callable] = None, defer_gather: bool = False):
+        """defer_gather: return from step() with the parameter all-gathers still in flight; the wrapped module's next
+        forward (or DataParallel.state_dict / params_ready()) makes the compute stream wait for them. Off by default:
+        code that reads `dp.module` parameters right after step() then needs no extra call."""
         if dp.sharded is None:
             raise RuntimeError("ShardedAdam needs DataParallel(..., shard_optimizer=True)")
         self.dp, self.lr, self.betas, self.eps = dp, lr, betas, eps
+        self.defer_gather = defer_gather
         self.kernel = kernel or _hip_adam_rows
         self.steps = 0
 
@@ -296,7 +324,7 @@ class ShardedAdam:
         b1, b2 = self.betas
         self.kernel(self.dp.sharded.rows(), self.lr, b1, b2, self.eps, 1.0 - b1 ** self.steps,
                     math.sqrt(1.0 - b2 ** self.steps))
-        self.dp.gather_parameters()
+        self.dp.gather_parameters(wait=not self.defer_gather)
 
     def state_dict(self) -> dict:
         sh = self.dp.sharded

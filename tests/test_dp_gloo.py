@@ -220,8 +220,15 @@ def _worker_sharded(rank: int, world: int, port: int, out_dir: str):
         params = [q for g in plan.groups for q in g]
         m = torch.zeros(plan.total)
         v = torch.zeros(plan.total)
-        opt = ShardedAdam(dp, lr=1e-3, kernel=_cpu_adam_rows) if shard else None
+        opt = ShardedAdam(dp, lr=1e-3, kernel=_cpu_adam_rows, defer_gather=(world == 2)) if shard else None
         for step in range(3):
+            if step == 2:
+                # resume / re-initialisation AFTER wrapping: an in-place load must be what the next step starts
+                # from. A rank shard that was a stale copy of the flat buffer would silently revert it.
+                if shard:
+                    dp.params_ready()
+                sd_new = OrderedDict((k, (v * 0.5 + 0.01) if v.is_floating_point() else v) for k, v in net.state_dict().items())
+                net.load_state_dict(sd_new)
             gen = torch.Generator().manual_seed(77 * step + rank)
             flat = torch.randn(plan.total, generator=gen) * 1e-2
             plan.sink = _FakeSink(flat)
@@ -236,8 +243,12 @@ def _worker_sharded(rank: int, world: int, port: int, out_dir: str):
         return OrderedDict((k, p.detach().clone()) for k, p in net.named_parameters()), dp
 
     plain, _ = run(False)
-    sharded, dp = run(True)
+    sharded_run = run(True)
+    sharded_run[1].params_ready()
+    sharded, dp = OrderedDict((k, p.detach().clone()) for k, p in sharded_run[1].module.named_parameters()), sharded_run[1]
     assert all(p.grad is None for p in dp.module.parameters())
+    assert all(sh.data_ptr() == dp.flat_p.data_ptr() + 4 * (b + rank * sh.numel())
+               for (b, e), sh in zip(dp.sharded.bounds, dp.sharded.p))          # the shard IS the flat buffer's slice
     # state_dict still has the reference's 154 keys and the parameters are views of the flat buffer
     assert len(dp.module.state_dict()) == 154
     base, n = dp.flat_p.data_ptr(), dp.flat_p.numel() * 4
@@ -250,10 +261,14 @@ def _worker_sharded(rank: int, world: int, port: int, out_dir: str):
     dist.destroy_process_group()
 
 
-def test_sharded_adam_equals_allreduce_adam_bitwise(tmp_path):
-    port = 33000 + (os.getpid() % 2000)
-    mp.spawn(_worker_sharded, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0, r1 = torch.load(tmp_path / "sh0.pt"), torch.load(tmp_path / "sh1.pt")
-    assert r0["same"] and r1["same"] and r0["moved"]
-    assert torch.equal(r0["w"], r1["w"])
-    assert r0["shard_elems"] * 2 == r0["total"]           # each rank holds (and updates) half of the optimizer state
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_adam_equals_allreduce_adam_bitwise(tmp_path, world):
+    """reduce-scatter -> Adam on the 1/world shard -> in-place all-gather gives the parameters of all-reduce + Adam bit
+    for bit, at world 2 (deferred all-gather waits) and at world 8 (the 8-GPU node's rank count), including a
+    load_state_dict between steps."""
+    port = 33000 + (os.getpid() % 2000) + world
+    mp.spawn(_worker_sharded, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(tmp_path / f"sh{r}.pt") for r in range(world)]
+    assert all(r["same"] for r in rs) and rs[0]["moved"]
+    assert all(torch.equal(rs[0]["w"], r["w"]) for r in rs)
+    assert rs[0]["shard_elems"] * world == rs[0]["total"]           # each rank holds (and updates) 1/world of the optimizer state

@@ -79,3 +79,50 @@ def test_graph_refuses_what_it_cannot_capture(dev):
         iu.GraphedTrainStep(net, iu.CrossEntropyLoss(ignore_index=255), iu.Adam(net.parameters()), x, y)
     with pytest.raises(iu.InsarError, match="no CPU fallback"):
         iu.GraphedTrainStep(net.train(), iu.CrossEntropyLoss(ignore_index=255), iu.Adam(net.parameters()), x.cpu(), y.cpu())
+
+
+def test_optimizer_state_loaded_after_the_capture_is_what_the_replay_uses(dev):
+    """Resume scenario: a GraphedTrainStep exists, then model and optimizer state are loaded from a checkpoint.
+    Adam.load_state_dict restores into the tensors the captured kernels point at (moments, device-side step state), so the
+    replayed steps continue the CHECKPOINT's trajectory bit for bit; a load that has to re-allocate state makes the next
+    replay raise instead of updating freed memory."""
+    import copy
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd.data import make_batch
+    batches = [tuple(t.to(dev) for t in make_batch(4 * i, 4, 32, channels=2)) for i in range(3)]
+
+    def fresh():
+        torch.manual_seed(5)
+        net = iu.UNet(2, 2, True, compute_dtype=torch.float32).to(dev).train()
+        return net, iu.DiceCELoss(ignore_index=255), iu.Adam(net.parameters(), lr=1e-3)
+
+    # run A: 5 eager steps, checkpoint, 3 more eager steps
+    net, crit, opt = fresh()
+    def eager(n, first):
+        out = []
+        for i in range(first, first + n):
+            x, y = batches[i % 3]
+            opt.zero_grad(set_to_none=True)
+            l = crit(net(x), y); l.backward(); opt.step(); out.append(float(l))
+        return out
+    eager(5, 0)
+    ck_model = copy.deepcopy(net.state_dict()); ck_opt = copy.deepcopy(opt.state_dict())
+    tail_a = eager(3, 5)
+    params_a = {k: v.clone() for k, v in net.state_dict().items()}
+    # run B: another trajectory, captured; then the checkpoint is loaded into the live objects
+    net, crit, opt = fresh()
+    step = iu.GraphedTrainStep(net, crit, opt, batches[2][0], batches[2][1], warmup=2)
+    step(*batches[1])
+    net.load_state_dict(ck_model)
+    gen = opt.generation
+    opt.load_state_dict(ck_opt)
+    assert opt.generation == gen, "same-shape state must be restored in place"
+    tail_b = [float(step(*batches[i % 3])) for i in range(5, 8)]
+    assert tail_a == tail_b, (tail_a, tail_b)
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, params_a[k]), k
+    assert float(opt.state_dict()["state"][0]["step"]) == 8
+    # a load that re-allocates (fresh optimizer state for other shapes) is refused at replay time
+    opt.generation += 1
+    with pytest.raises(iu.InsarError, match="re-allocated"):
+        step(*batches[0])

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--B", type=int, default=16)
     ap.add_argument("--what", default="fwd,dgrad,flat,wgrad")
+    ap.add_argument("--knob", default="", help="with --what knob-wgrad / knob-fwd / knob-dgrad: name=v0,v1[,v2...] library knob to A/B")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -100,6 +101,42 @@ def main():
             st2 = torch.zeros(rows, 2, cout, device=dev)
             us = run(lambda: call("insar_conv3x3_flat", x.ref, y.ref, ptr(wf), 0, ptr(st2), _lib.stream_ptr())); res.append(f"flat-fwd {us:7.1f} us {flops/us/1e6:7.1f} TF")
             us = run(lambda: call("insar_conv3x3_flat", g.ref, dx.ref, ptr(wd), 1, 0, _lib.stream_ptr())); res.append(f"flat-dgrad {us:7.1f} us {flops/us/1e6:7.1f} TF")
+        for mode in [w for w in what if w.startswith("knob-")]:
+            # same-process A/B of a library knob (insar_tune_set): interleaved rounds, min / median, results compared
+            kname, _, vals = a.knob.partition("=")
+            vals = [int(v) for v in vals.split(",")]
+            fn = {"knob-wgrad": lambda: call("insar_wgrad_conv3", x.ref, g.ref, _lib.ptr(part_), nsp_, _lib.stream_ptr()),
+                  "knob-fwd": lambda: engine._igemm(x, y, wf, cout, hw, hw, 1, engine._TAPS3, 0, stats=stats),
+                  "knob-dgrad": lambda: engine._igemm(g, dx, wd, cin, hw, hw, 1, engine._TAPS3_DGRAD, 0)}[mode]
+            if mode == "knob-wgrad":
+                pair = call("insar_wgrad_conv3_tile", x.ref, cout)
+                if not pair:
+                    continue
+                tm, tn = pair >> 16, pair & 0xffff
+                tiles = 3 * (cin // tm) * (cout // tn)
+                nsp_ = engine._wgrad_nsplit(tiles, M // 64, 9 * cout * cin, tm, tn, 2, taps_per_wg=3, fill=1.0)
+                part_ = ctx.wgrad_part(nsp_ * 9 * cout * cin)
+            rounds = {v: [] for v in vals}
+            outs = {}
+            for r in range(5):
+                for v in vals:
+                    _lib.tune(kname, v)
+                    rounds[v].append(run(fn))
+            for v in vals:
+                _lib.tune(kname, v)
+                if mode == "knob-wgrad":
+                    part_.zero_(); fn(); torch.cuda.synchronize(); outs[v] = part_[:nsp_ * 9 * cout * cin].clone()
+                elif mode == "knob-fwd":
+                    y.buf.zero_(); fn(); torch.cuda.synchronize(); outs[v] = y.buf.float().clone()
+                else:
+                    dx.buf.zero_(); fn(); torch.cuda.synchronize(); outs[v] = dx.buf.float().clone()
+                t = sorted(rounds[v])
+                res.append(f"\n   {mode} {kname}={v}: min {t[0]:6.1f} med {t[len(t)//2]:6.1f} us ({flops/t[0]/1e6:6.0f} / {flops/t[len(t)//2]/1e6:6.0f} TF)")
+            _lib.tune(kname, vals[0])
+            ref = outs[vals[0]]
+            for v in vals[1:]:
+                d = (outs[v] - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
+                res.append(f"max|{kname}={v} - {kname}={vals[0]}|/max = {d:.2e}" + (" (bitwise)" if torch.equal(outs[v], ref) else ""))
         if "wgrad" in what:
             us = run(lambda: engine._wgrad_conv3(ctx, x, g, grad)); res.append(f"wgrad(+fold) {us:7.1f} us {flops/us/1e6:7.1f} TF")
         print(f"{name:9s} {cin:4d}->{cout:4d} @{hw:3d}^2 tile_rows {call('insar_igemm_tile_rows', M, cout)}: " + " | ".join(res), flush=True)
