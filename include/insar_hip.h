@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define INSAR_ABI_VERSION 2
+#define INSAR_ABI_VERSION 3
 
 enum { INSAR_F32 = 0, INSAR_BF16 = 1 };
 
@@ -90,6 +90,18 @@ int insar_weight_prep_pair_batch(const int64_t* jobs, int32_t njobs, int64_t tot
  *         is scattered to out pixel (2ho+a, 2wo+b), channel co.
  * stats (nullable): per-M-tile partial column sums of the stored output,
  *         float[insar_igemm_num_mtiles(M, N)][2][N] (sum, sum of squares) for BatchNorm (:82,85). */
+/* BatchNorm-backward sums taken in the epilogue of the GEMM that PRODUCES a unit's incoming gradient ("bstat"), instead of
+ * a pass of its own over (dout, y) (insar_bnrelu_bwd_reduce; :82-83,85-86 inside loss.backward(), :345): with g = the
+ * stored output element and yv = y at the same (pixel, channel),
+ *   stats[row][0][n] = sum_pixels g * [scale[n]*yv + shift[n] > 0],   stats[row][1][n] = sum_pixels g * [...] * yv
+ * in the slab the forward statistics would use (same rows). y = the consumer unit's raw conv output in a buffer with the
+ * OUTPUT's layout (same B, H, W, C, c_off, dtype); y == NULL switches the mode off. */
+typedef struct InsarBstat {
+  const void* y;
+  const float* scale;
+  const float* shift;
+} InsarBstat;
+
 typedef struct InsarIgemm {
   InsarAct x;          /* input slice, c_len = K per tap */
   InsarAct y;          /* output slice */
@@ -107,6 +119,7 @@ typedef struct InsarIgemm {
   int32_t out_oy, out_ox; /*   wo*s + out_ox) — one parity class of the input gradient of a stride-s convolution */
   int32_t _pad;
   const void* add;     /* nullable, mode 0: a tensor with y's buffer layout (same C, c_off, dtype), added to the result */
+  InsarBstat bstat;    /* mode 0, dense output, with stats: BatchNorm-backward sums instead of (sum, sum of squares) */
 } InsarIgemm;
 /* flags. OOB_ZERO: taps may leave the padded input and read zeros there (dilated 3x3 convolutions of DeepLabV3's
  * layer3 / layer4 / ASPP, torchvision resnet.py / deeplabv3.py; the 1-pixel halo covers only |dy|,|dx| <= 1). */
@@ -137,6 +150,9 @@ int insar_conv3x3_flat_num_mtiles(const InsarAct* x);
 int insar_conv3x3_flat_stat_rows(const InsarAct* x, int32_t N, int32_t flip);
 int insar_conv3x3_flat(const InsarAct* x, const InsarAct* y, const void* w, int32_t flip, float* stats,
                        void* stream);
+/* the same with BatchNorm-backward sums in the statistics slab (InsarBstat above; bstat->y has y's layout) */
+int insar_conv3x3_flat_bstat(const InsarAct* x, const InsarAct* y, const void* w, int32_t flip, float* stats,
+                             const InsarBstat* bstat, void* stream);
 
 /* ---- 3x3 conv with 64 -> 64 channels, bf16 (the full-resolution level; :81,84 and their dgrad) -------
  * Persistent work-groups, weights in registers, activations through a rolling LDS window over the flat
@@ -148,6 +164,9 @@ int insar_conv3x3_c64_rows(const InsarAct* x);
 int insar_conv3x3_c64_geometry(const InsarAct* x, int32_t* out);
 int insar_conv3x3_c64(const InsarAct* x, const InsarAct* y, const void* w, int32_t flip, float* stats,
                       void* stream);
+/* the same with BatchNorm-backward sums in the statistics slab (InsarBstat; scale / shift 16-byte aligned) */
+int insar_conv3x3_c64_bstat(const InsarAct* x, const InsarAct* y, const void* w, int32_t flip, float* stats,
+                            const InsarBstat* bstat, void* stream);
 
 /* ---- weight-gradient GEMM (MFMA, split-K over pixels, no atomics) ------------------------------
  * part[split][tap][co][ci] = sum_{p in split} dy[pixB(p,tap), co] * x[pixA(p,tap), ci]

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INSAR_HIP_LIB") or os.path.join(_HERE, "libinsar_hip.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 IGEMM_OOB_ZERO = 1
 IGEMM_PINGPONG = 2
 
@@ -26,12 +26,16 @@ class InsarAct(C.Structure):
                 ("_pad", C.c_int32)]
 
 
+class InsarBstat(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p)]
+
+
 class InsarIgemm(C.Structure):
     _fields_ = [("x", InsarAct), ("y", InsarAct), ("w", C.c_void_p), ("bias", C.c_void_p),
                 ("stats", C.c_void_p), ("N", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
                 ("stride", C.c_int32), ("ntaps", C.c_int32), ("mode", C.c_int32),
                 ("dy", C.c_int8 * 12), ("dx", C.c_int8 * 12), ("flags", C.c_int32), ("out_stride", C.c_int32),
-                ("out_oy", C.c_int32), ("out_ox", C.c_int32), ("_pad", C.c_int32), ("add", C.c_void_p)]
+                ("out_oy", C.c_int32), ("out_ox", C.c_int32), ("_pad", C.c_int32), ("add", C.c_void_p), ("bstat", InsarBstat)]
 
 
 class InsarWgrad(C.Structure):
@@ -96,10 +100,12 @@ _SIGNATURES = {
     "insar_conv3x3_flat_num_mtiles": [_AP],
     "insar_conv3x3_flat_stat_rows": [_AP, _I, _I],
     "insar_conv3x3_flat": [_AP, _AP, _P, _I, _P, _P],
+    "insar_conv3x3_flat_bstat": [_AP, _AP, _P, _I, _P, C.POINTER(InsarBstat), _P],
     "insar_conv3x3_c64_ok": [_AP, _I],
     "insar_conv3x3_c64_rows": [_AP],
     "insar_conv3x3_c64_geometry": [_AP, _P],
     "insar_conv3x3_c64": [_AP, _AP, _P, _I, _P, _P],
+    "insar_conv3x3_c64_bstat": [_AP, _AP, _P, _I, _P, C.POINTER(InsarBstat), _P],
     "insar_wgrad": [C.POINTER(InsarWgrad), _P],
     "insar_wgrad_tile": [_I, _I],
     "insar_wgrad_tile_pair": [_I, _I, _I],

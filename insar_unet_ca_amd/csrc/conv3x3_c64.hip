@@ -38,6 +38,7 @@ struct C64Args {
   int o;                       // tile origin shift: Af - A (<= 0)
   int R;                       // ring rows (multiple of 64)
   int ntiles;
+  const char* by; const float* bscale; const float* bshift;   // BatchNorm-backward sums in the stats slab (InsarBstat)
 };
 
 __device__ __forceinline__ void c6_mma(const uint4& wa, const uint4& xb, f32x4_t& acc) {
@@ -45,7 +46,8 @@ __device__ __forceinline__ void c6_mma(const uint4& wa, const uint4& xb, f32x4_t
 }
 
 // NTW = 16-channel tiles per wave along N (2: N = 64 with waves 4(M) x 2(N), wave tile 64 x 32)
-template <int NTW>
+// BS: BatchNorm-backward sums of the consumer unit in the statistics slab (InsarBstat) instead of (sum, sum of squares)
+template <int NTW, bool BS = false>
 __global__ __launch_bounds__(C6_THREADS, 1) void conv3x3_c64_kernel(C64Args a) {
   constexpr int MT = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -134,6 +136,52 @@ __global__ __launch_bounds__(C6_THREADS, 1) void conv3x3_c64_kernel(C64Args a) {
       hr = (int)((float)rem * a.inv_wp);
       wc = rem - hr * Wp;
       if (wc < 0) { wc += Wp; --hr; } else if (wc >= Wp) { wc -= Wp; ++hr; }
+    }
+    if constexpr (BS) {
+      // the consumer's y at this lane's 4 pixels x 2 x 4 channels, all requested before the first use; its scale / shift
+      // re-read per tile (L2 hits) rather than held in 16 registers beside the 144 of the weights
+      bool okm[MT];
+      uint2 yv[MT][NTW];
+      long long off[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int q = qt + lrow + mt * 16;
+        if (mt > 0) {
+          wc += 16;
+          if (wc >= Wp) { wc -= Wp; ++hr; if (hr >= a.H + 2) hr = 0; }
+        }
+        okm[mt] = q >= 0 && q <= Pm1 && hr >= 1 && hr <= a.H && wc >= 1 && wc <= a.W;
+        off[mt] = ((long long)q * a.Cy + a.cy_off + wn * (16 * NTW) + kq * 4) * 2;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) yv[mt][nt] = okm[mt] ? *(const uint2*)(a.by + off[mt] + nt * 32) : make_uint2(0u, 0u);
+      }
+      f32x4_t bsc[NTW], bsh[NTW];
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        bsc[nt] = *(const f32x4_t*)(a.bscale + wn * (16 * NTW) + nt * 16 + kq * 4);
+        bsh[nt] = *(const f32x4_t*)(a.bshift + wn * (16 * NTW) + nt * 16 + kq * 4);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        if (okm[mt]) {
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) {
+            uint2 v;
+            v.x = pack2_bf16(acc[nt][mt][0], acc[nt][mt][1]);
+            v.y = pack2_bf16(acc[nt][mt][2], acc[nt][mt][3]);
+            *(uint2*)(a.y + off[mt] + nt * 32) = v;
+            const float f[4] = {__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                                __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
+            const float yy[4] = {__uint_as_float(yv[mt][nt].x << 16), __uint_as_float(yv[mt][nt].x & 0xffff0000u),
+                                 __uint_as_float(yv[mt][nt].y << 16), __uint_as_float(yv[mt][nt].y & 0xffff0000u)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float m = fmaf(yy[j], bsc[nt][j], bsh[nt][j]) > 0.f ? f[j] : 0.f;
+              s1[nt][j] += m; s2[nt][j] = fmaf(m, yy[j], s2[nt][j]);
+            }
+          }
+        }
+      return;
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -317,8 +365,8 @@ extern "C" int insar_conv3x3_c64_rows(const InsarAct* x) {
 
 // y = conv3x3(x, w), 64 -> 64 channels, same (B, H, W) grid. w: [9][64][64] bf16 in (dy, dx) raster order;
 // flip != 0 walks the taps backwards (the dgrad operand of insar_weight_prep). stats: [rows][2][64] or null.
-extern "C" int insar_conv3x3_c64(const InsarAct* x, const InsarAct* y, const void* w, int32_t flip, float* stats,
-                                 void* stream) {
+static int c64_impl(const InsarAct* x, const InsarAct* y, const void* w, int32_t flip, float* stats, const InsarBstat* bstat,
+                    void* stream) {
   if (!x || !y || !w) INSAR_FAIL(INSAR_E_ARG, "insar_conv3x3_c64: null pointer");
   int rc;
   if ((rc = insar_check_act(x, "insar_conv3x3_c64", "x"))) return rc;
@@ -332,15 +380,33 @@ extern "C" int insar_conv3x3_c64(const InsarAct* x, const InsarAct* y, const voi
   a.x = (const char*)x->ptr; a.w = (const char*)w; a.y = (char*)y->ptr; a.stats = stats;
   a.Cx = x->C; a.cx_off = x->c_off; a.Cy = y->C; a.cy_off = y->c_off; a.N = 64;
   a.flip = flip ? 1 : 0;
+  a.by = nullptr; a.bscale = a.bshift = nullptr;
+  if (bstat && bstat->y) {
+    if (!stats || !bstat->scale || !bstat->shift) INSAR_FAIL(INSAR_E_ARG, "insar_conv3x3_c64_bstat: needs a stats slab, scale and shift");
+    if (!insar_aligned16(bstat->y) || !insar_aligned16(bstat->scale) || !insar_aligned16(bstat->shift))
+      INSAR_FAIL(INSAR_E_ALIGN, "insar_conv3x3_c64_bstat: bstat pointers not 16-byte aligned");
+    a.by = (const char*)bstat->y; a.bscale = bstat->scale; a.bshift = bstat->shift;
+  }
   const int lds = a.R * C6_ROWB + 8 * 64 * 2 * 4;
-  static std::atomic<uint64_t> attr_mask{0};     // per-device, see common.h
+  static std::atomic<uint64_t> attr_mask{0}, attr_mask_bs{0};     // per-device, see common.h
   {
-    hipError_t e = insar_set_lds_once(attr_mask, (const void*)conv3x3_c64_kernel<2>, C6_MAX_LDS);
+    hipError_t e = a.by ? insar_set_lds_once(attr_mask_bs, (const void*)conv3x3_c64_kernel<2, true>, C6_MAX_LDS)
+                        : insar_set_lds_once(attr_mask, (const void*)conv3x3_c64_kernel<2>, C6_MAX_LDS);
     if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_conv3x3_c64: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   const int cus = c64_num_cus();
   const int grid = a.ntiles < cus ? a.ntiles : cus;
-  hipLaunchKernelGGL((conv3x3_c64_kernel<2>), dim3(grid), dim3(C6_THREADS), lds, (hipStream_t)stream, a);
+  if (a.by) hipLaunchKernelGGL((conv3x3_c64_kernel<2, true>), dim3(grid), dim3(C6_THREADS), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((conv3x3_c64_kernel<2>), dim3(grid), dim3(C6_THREADS), lds, (hipStream_t)stream, a);
   INSAR_CHECK_LAUNCH("insar_conv3x3_c64");
   return INSAR_OK;
+}
+
+extern "C" int insar_conv3x3_c64(const InsarAct* x, const InsarAct* y, const void* w, int32_t flip, float* stats,
+                                 void* stream) {
+  return c64_impl(x, y, w, flip, stats, nullptr, stream);
+}
+extern "C" int insar_conv3x3_c64_bstat(const InsarAct* x, const InsarAct* y, const void* w, int32_t flip, float* stats,
+                                       const InsarBstat* bstat, void* stream) {
+  return c64_impl(x, y, w, flip, stats, bstat, stream);
 }

@@ -33,6 +33,7 @@ struct FlatArgs {
   int carry;                   // persistent + one N tile: BatchNorm sums carried over the tiles, slab row = blockIdx.x
   int num_mtiles, num_ntiles;
   int total_tiles;             // num_mtiles * num_ntiles
+  const char* by; const float* bscale; const float* bshift;   // BatchNorm-backward sums in the stats slab (InsarBstat)
 };
 
 template <typename T> struct FMma;
@@ -77,7 +78,9 @@ __device__ __forceinline__ void fl_wait_and_barrier() {
 // in igemm.hip: [load part: the step's fragment reads + the LDS-DMA pieces the plain loop issues in this step] -> s_barrier
 // -> [its 2*NT*MT MFMAs under s_setprio 1] -> s_barrier, group 1 one barrier behind group 0. A staged slab is waited for
 // one phase after it was issued and read one phase after that wait. Same accumulation order as the plain loop.
-template <typename T, int BN, bool PP = false>
+// BS: BatchNorm-backward sums in the statistics slab (InsarBstat; an instantiation of its own: the 128-column kernel is
+// at the register limit and the plain launches keep their code).
+template <typename T, int BN, bool PP = false, bool BS = false>
 __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a) {
   using Cfg = FlatCfg<T, BN>;
   constexpr int ES = Cfg::ES, BKe = Cfg::BKe, CH = Chunk<T>::N;
@@ -325,17 +328,46 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
   float s1[CH], s2[CH];
 #pragma unroll
   for (int j = 0; j < CH; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  // BS (see igemm.hip): the consumer unit's y at the output's positions, half of this thread's chunks requested at a time
+  float bsc[BS ? CH : 1], bsh[BS ? CH : 1];
+  if constexpr (BS) {
 #pragma unroll
-  for (int i = 0; i < ITER; ++i) {
-    const int row = i * RSTEP + tid / CPR;
-    const long long ro = rowOut[row];
-    if (ro >= 0) {
-      const uint4 u = *(const uint4*)(tile + row * Cfg::PITCH + cc * 16);
-      float f[CH];
-      Chunk<T>::unpack(u, f);
+    for (int j = 0; j < CH; ++j) { bsc[j] = a.bscale[col_off + j]; bsh[j] = a.bshift[col_off + j]; }
+  }
+  constexpr int HALF = ITER / 2;
+  static_assert(ITER % 2 == 0, "epilogue chunk batches");
 #pragma unroll
-      for (int j = 0; j < CH; ++j) { s1[j] += f[j]; s2[j] = fmaf(f[j], f[j], s2[j]); }
-      *(uint4*)(a.y + (ro + col_off) * ES) = u;
+  for (int i0 = 0; i0 < ITER; i0 += HALF) {
+    uint4 yv[BS ? HALF : 1];
+    if constexpr (BS) {
+#pragma unroll
+      for (int i = 0; i < HALF; ++i) {
+        const long long ro = rowOut[(i0 + i) * RSTEP + tid / CPR];
+        yv[i] = ro >= 0 ? *(const uint4*)(a.by + (ro + col_off) * ES) : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) {
+      const int row = (i0 + i) * RSTEP + tid / CPR;
+      const long long ro = rowOut[row];
+      if (ro >= 0) {
+        const uint4 u = *(const uint4*)(tile + row * Cfg::PITCH + cc * 16);
+        float f[CH];
+        Chunk<T>::unpack(u, f);
+        if constexpr (BS) {
+          float yy[CH];
+          Chunk<T>::unpack(yv[i], yy);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            const float m = fmaf(yy[j], bsc[j], bsh[j]) > 0.f ? f[j] : 0.f;
+            s1[j] += m; s2[j] = fmaf(m, yy[j], s2[j]);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < CH; ++j) { s1[j] += f[j]; s2[j] = fmaf(f[j], f[j], s2[j]); }
+        }
+        *(uint4*)(a.y + (ro + col_off) * ES) = u;
+      }
     }
   }
   if (a.stats && a.carry) {
@@ -425,12 +457,12 @@ extern "C" int insar_conv3x3_flat_stat_rows(const InsarAct* x, int32_t N, int32_
   return (cus >= 8 && grid > cus && N / bn == 1) ? cus : mt;
 }
 
-template <typename T, int BN, bool PP = false>
+template <typename T, int BN, bool PP = false, bool BS = false>
 static int launch_flat(FlatArgs& a, hipStream_t s) {
   using Cfg = FlatCfg<T, BN>;
   static std::atomic<uint64_t> attr_mask{0};     // per-device, see common.h
   {
-    hipError_t e = insar_set_lds_once(attr_mask, (const void*)conv3x3_flat_kernel<T, BN, PP>, Cfg::LDS_BYTES);
+    hipError_t e = insar_set_lds_once(attr_mask, (const void*)conv3x3_flat_kernel<T, BN, PP, BS>, Cfg::LDS_BYTES);
     if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_conv3x3_flat: hipFuncSetAttribute(%d bytes LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
   }
   a.num_ntiles = a.N / BN;
@@ -441,7 +473,7 @@ static int launch_flat(FlatArgs& a, hipStream_t s) {
     const int cus = insar_num_cus() & ~7;
     if (cus >= 8 && grid > cus) { grid = cus; a.carry = a.num_ntiles == 1 ? 1 : 0; }
   }
-  hipLaunchKernelGGL((conv3x3_flat_kernel<T, BN, PP>), dim3((unsigned)grid), dim3(FL_THREADS), Cfg::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((conv3x3_flat_kernel<T, BN, PP, BS>), dim3((unsigned)grid), dim3(FL_THREADS), Cfg::LDS_BYTES, s, a);
   INSAR_CHECK_LAUNCH("insar_conv3x3_flat");
   return INSAR_OK;
 }
@@ -449,8 +481,8 @@ static int launch_flat(FlatArgs& a, hipStream_t s) {
 // y = conv3x3(x, w) over the same (B, H, W) grid. w: [9][N][K] in (dy, dx) raster order of the FORWARD
 // taps; flip != 0 walks the slabs backwards (the dgrad operand produced by insar_weight_prep keeps the
 // forward raster order of (r, s), whose spatial offsets are (1-r, 1-s)).
-extern "C" int insar_conv3x3_flat(const InsarAct* x, const InsarAct* y, const void* w, int32_t flip, float* stats,
-                                  void* stream) {
+static int flat_impl(const InsarAct* x, const InsarAct* y, const void* w, int32_t flip, float* stats, const InsarBstat* bstat,
+                     void* stream) {
   if (!x || !y || !w) INSAR_FAIL(INSAR_E_ARG, "insar_conv3x3_flat: null pointer");
   int rc;
   if ((rc = insar_check_act(x, "insar_conv3x3_flat", "x"))) return rc;
@@ -466,6 +498,12 @@ extern "C" int insar_conv3x3_flat(const InsarAct* x, const InsarAct* y, const vo
   if (P >= 0x7fffffffLL) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: too many pixels");
   FlatArgs a;
   a.x = (const char*)x->ptr; a.w = (const char*)w; a.y = (char*)y->ptr; a.stats = stats;
+  a.by = nullptr; a.bscale = a.bshift = nullptr;
+  if (bstat && bstat->y) {
+    if (!stats || !bstat->scale || !bstat->shift) INSAR_FAIL(INSAR_E_ARG, "insar_conv3x3_flat_bstat: needs a stats slab, scale and shift");
+    if (!insar_aligned16(bstat->y)) INSAR_FAIL(INSAR_E_ALIGN, "insar_conv3x3_flat_bstat: bstat.y not 16-byte aligned");
+    a.by = (const char*)bstat->y; a.bscale = bstat->scale; a.bshift = bstat->shift;
+  }
   a.P = P; a.B = x->B; a.H = x->H; a.W = x->W;
   a.Cx = x->C; a.cx_off = x->c_off; a.K = x->c_len;
   a.Cy = y->C; a.cy_off = y->c_off; a.N = y->c_len;
@@ -474,7 +512,20 @@ extern "C" int insar_conv3x3_flat(const InsarAct* x, const InsarAct* y, const vo
   a.num_mtiles = flat_mtiles(P);
   hipStream_t s = (hipStream_t)stream;
   const bool wide = (a.N % 128) == 0;
+  if (a.by) {           // bf16: the ping-pong loop whatever the flag says (same results bit for bit)
+    if (x->dtype == INSAR_BF16) return wide ? launch_flat<bf16_t, 128, true, true>(a, s) : launch_flat<bf16_t, 64, true, true>(a, s);
+    return wide ? launch_flat<float, 128, false, true>(a, s) : launch_flat<float, 64, false, true>(a, s);
+  }
   if (x->dtype == INSAR_BF16 && pp) return wide ? launch_flat<bf16_t, 128, true>(a, s) : launch_flat<bf16_t, 64, true>(a, s);
   if (x->dtype == INSAR_BF16) return wide ? launch_flat<bf16_t, 128>(a, s) : launch_flat<bf16_t, 64>(a, s);
   return wide ? launch_flat<float, 128>(a, s) : launch_flat<float, 64>(a, s);
+}
+
+extern "C" int insar_conv3x3_flat(const InsarAct* x, const InsarAct* y, const void* w, int32_t flip, float* stats,
+                                  void* stream) {
+  return flat_impl(x, y, w, flip, stats, nullptr, stream);
+}
+extern "C" int insar_conv3x3_flat_bstat(const InsarAct* x, const InsarAct* y, const void* w, int32_t flip, float* stats,
+                                        const InsarBstat* bstat, void* stream) {
+  return flat_impl(x, y, w, flip, stats, bstat, stream);
 }

@@ -39,6 +39,7 @@ struct IgemmArgs {
   signed char tdy[12], tdx[12];   // the taps themselves (OOB variant: per-row bounds test)
   int out_stride, out_oy, out_ox;   // mode 0: row (ho, wo) is stored at output pixel (ho*out_stride + out_oy, wo*out_stride + out_ox)
   const char* add; // nullable: tensor with y's layout added to the result in the epilogue (residual / gradient sum)
+  const char* by; const float* bscale; const float* bshift;   // BatchNorm-backward sums in the stats slab (InsarBstat)
 };
 
 __device__ __forceinline__ void lds_dma16(const char* gsrc, char* lds_wave_base) {
@@ -365,6 +366,18 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
   float s1[CH], s2[CH];
 #pragma unroll
   for (int j = 0; j < CH; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  // bstat: the consumer unit's y at the output's positions, all of this thread's chunks requested before the first is used
+  uint4 yv[ITER];
+  float bsc[CH], bsh[CH];
+  if (a.by) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { bsc[j] = a.bscale[ncol + j]; bsh[j] = a.bshift[ncol + j]; }
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const long long ro = rowOut[i * RSTEP + tid / CPR];
+      yv[i] = ro >= 0 ? *(const uint4*)(a.by + (ro + col_off) * ES) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < ITER; ++i) {
     const int row = i * RSTEP + tid / CPR;
@@ -372,8 +385,20 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
     if (ro >= 0) {
       float f[CH];
       Chunk<T>::unpack(*(const uint4*)(tile + row * Cfg::PITCH + cc * 16), f);
+      if (a.by) {
+        float yy[CH];
+        Chunk<T>::unpack(yv[i], yy);
 #pragma unroll
-      for (int j = 0; j < CH; ++j) { s1[j] += f[j]; s2[j] = fmaf(f[j], f[j], s2[j]); f[j] += bias[j]; }
+        for (int j = 0; j < CH; ++j) {
+          const float m = fmaf(yy[j], bsc[j], bsh[j]) > 0.f ? f[j] : 0.f;
+          s1[j] += m; s2[j] = fmaf(m, yy[j], s2[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { s1[j] += f[j]; s2[j] = fmaf(f[j], f[j], s2[j]); }
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) f[j] += bias[j];
       if (a.add) {
         float g[CH];
         Chunk<T>::unpack(*(const uint4*)(a.add + (ro + col_off) * ES), g);
@@ -518,6 +543,12 @@ extern "C" int insar_igemm(const InsarIgemm* d, void* stream) {
     a.tdy[t] = t < d->ntaps ? d->dy[t] : 0; a.tdx[t] = t < d->ntaps ? d->dx[t] : 0;
   }
   a.add = (const char*)d->add;
+  a.by = (const char*)d->bstat.y; a.bscale = d->bstat.scale; a.bshift = d->bstat.shift;
+  if (a.by) {
+    if (d->mode != 0 || os != 1 || !d->stats || !a.bscale || !a.bshift || d->bias || d->add)
+      INSAR_FAIL(INSAR_E_ARG, "insar_igemm: bstat needs mode 0, a dense output, a stats slab, scale / shift, no bias, no add");
+    if (!insar_aligned16(a.by)) INSAR_FAIL(INSAR_E_ALIGN, "insar_igemm: bstat.y not 16-byte aligned");
+  }
   a.out_stride = os; a.out_oy = d->mode == 0 ? d->out_oy : 0; a.out_ox = d->mode == 0 ? d->out_ox : 0;
   hipStream_t s = (hipStream_t)stream;
   const bool wide = igemm_bn_for(a.M, d->N) == 128;

@@ -278,6 +278,7 @@ WGRAD_ROWS = os.environ.get("INSAR_WGRAD_ROWS", "1") != "0"      # diagnostic: 0
 FLAT_PP = int(os.environ.get("INSAR_FLAT_PP", "1"))               # flat 3x3 kernel: ping-pong tap steps (0 = plain loop; bitwise equal)
 FLAT_PERSIST = int(os.environ.get("INSAR_FLAT_PERSIST", "1"))     # flat 3x3 kernel: one work-group per CU walking its tiles (bitwise equal): 1 = forward launches, 2 = all, 0 = off
 IGEMM_PP = int(os.environ.get("INSAR_IGEMM_PP", "1"))            # 256 x 256 tiles: ping-pong K loop (0 = the plain two-slab loop; bitwise equal)
+BSTAT_FUSE = os.environ.get("INSAR_BSTAT_FUSE", "1") != "0"      # diagnostic: 0 = BatchNorm-backward sums always in a pass of their own
 WGRAD_LATE = os.environ.get("INSAR_WGRAD_ORDER", "before") == "after"      # diagnostic / tuning switch, see ConvBN.backward
 
 
@@ -288,9 +289,12 @@ _TAPS2 = [(a, b) for a in range(2) for b in range(2)]
 
 def _igemm(x: Act, y: Act, w, N: int, Ho: int, Wo: int, stride: int, taps, mode: int,
            bias: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, oob: bool = False,
-           add: Optional[Act] = None, out_stride: int = 1, out_off=(0, 0)) -> None:
-    """w: tensor, or a raw device pointer (a tap slice of a GEMM-layout weight)."""
+           add: Optional[Act] = None, out_stride: int = 1, out_off=(0, 0), bstat=None) -> None:
+    """w: tensor, or a raw device pointer (a tap slice of a GEMM-layout weight). bstat = (y Act, scale, shift): the stats
+    slab receives the BatchNorm-backward sums of the unit that consumes this GEMM's output (InsarBstat)."""
     d = InsarIgemm()
+    if bstat is not None:
+        d.bstat.y, d.bstat.scale, d.bstat.shift = bstat[0].buf.data_ptr(), ptr(bstat[1]), ptr(bstat[2])
     d.x, d.y = x.desc, y.desc
     d.w, d.bias, d.stats = (w if isinstance(w, int) else ptr(w)), ptr(bias), ptr(stats)
     d.N, d.Ho, d.Wo, d.stride, d.ntaps, d.mode = N, Ho, Wo, stride, len(taps), mode
@@ -324,22 +328,31 @@ def _flat_persist(flip: int) -> bool:
     return FLAT_PERSIST == 2 or (FLAT_PERSIST == 1 and not (flip & 1))
 
 
-def _conv3x3_flat(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[torch.Tensor]) -> None:
+def _conv3x3_flat(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[torch.Tensor], bstat=None) -> None:
+    flags = flip | (2 if FLAT_PP else 0) | (4 if _flat_persist(flip) else 0)
+    if bstat is not None:
+        bs = _lib.InsarBstat(bstat[0].buf.data_ptr(), ptr(bstat[1]), ptr(bstat[2]))
+        fn = lambda: call("insar_conv3x3_flat_bstat", x.ref, y.ref, ptr(w), flags, ptr(stats), C.byref(bs), _lib.stream_ptr())
+    else:
+        fn = lambda: call("insar_conv3x3_flat", x.ref, y.ref, ptr(w), flags, ptr(stats), _lib.stream_ptr())
     if PROFILER is not None:
         flops = 2.0 * x.B * x.H * x.W * y.c_len * x.c_len * 9
         tag = "conv3x3_flat_kernel<%s, %d>" % ("float" if x.code == _lib.F32 else "bf16_t", 128 if y.c_len % 128 == 0 else 64)
-        PROFILER.run(tag, flops, lambda: call("insar_conv3x3_flat", x.ref, y.ref, ptr(w), flip | (2 if FLAT_PP else 0) | (4 if _flat_persist(flip) else 0), ptr(stats), _lib.stream_ptr()))
+        PROFILER.run(tag, flops, fn)
         return
-    call("insar_conv3x3_flat", x.ref, y.ref, ptr(w), flip | (2 if FLAT_PP else 0) | (4 if _flat_persist(flip) else 0), ptr(stats), _lib.stream_ptr())
+    fn()
 
 
-def _conv3x3_c64(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[torch.Tensor]) -> None:
+def _conv3x3_c64(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[torch.Tensor], bstat=None) -> None:
+    if bstat is not None:
+        bs = _lib.InsarBstat(bstat[0].buf.data_ptr(), ptr(bstat[1]), ptr(bstat[2]))
+        fn = lambda: call("insar_conv3x3_c64_bstat", x.ref, y.ref, ptr(w), flip, ptr(stats), C.byref(bs), _lib.stream_ptr())
+    else:
+        fn = lambda: call("insar_conv3x3_c64", x.ref, y.ref, ptr(w), flip, ptr(stats), _lib.stream_ptr())
     if PROFILER is not None:
-        flops = 2.0 * x.B * x.H * x.W * 64 * 64 * 9
-        PROFILER.run("conv3x3_c64_kernel<2>", flops,
-                     lambda: call("insar_conv3x3_c64", x.ref, y.ref, ptr(w), flip, ptr(stats), _lib.stream_ptr()))
+        PROFILER.run("conv3x3_c64_kernel<2>", 2.0 * x.B * x.H * x.W * 64 * 64 * 9, fn)
         return
-    call("insar_conv3x3_c64", x.ref, y.ref, ptr(w), flip, ptr(stats), _lib.stream_ptr())
+    fn()
 
 
 def _wgrad_tiles(cin: int, cout: int, code: int):
@@ -521,6 +534,22 @@ class ConvBN:
         self.bwd_ws = ctx.f32(B * (3 * self.cout + max(self.cout // 16, 1)))
         self.dy = None            # gradient wrt the raw conv output (allocated on first backward)
         self.w = None if self.small else GemmWeight(ctx, conv.weight, "conv3")
+        # BatchNorm-backward sums written by the epilogue of the GEMM that produces this unit's incoming gradient
+        # (InsarBstat): slab [B * bred_rows][2][C]; bred_ready is set by that GEMM's launch and consumed by backward()
+        self.bred, self.bred_rows, self.bred_ready = None, 0, False
+
+    def bstat_slab(self, rows_total: int, per_image: bool):
+        """(slab, (y, scale, shift)) for a producer GEMM whose statistics slab has `rows_total` rows, or None if this unit
+        cannot take its backward sums from it. per_image: the rows are whole-image groups in image order (an SE unit's
+        coefficient stage folds them per image); else any partition will do and the slab is padded with zero rows to a
+        multiple of B (the coefficient stage sums B equal groups)."""
+        B = self.x.B
+        if per_image and rows_total % B:
+            return None
+        rows = -(-rows_total // B)
+        if self.bred is None or self.bred_rows != rows:
+            self.bred, self.bred_rows = self.ctx.f32(B * rows, 2, self.cout), rows
+        return self.bred, (self.y, self.scale, self.shift)
 
     # ---- forward: y = conv(x); BN statistics; scale/shift ---------------------------------------
     def forward_conv(self, training: bool, sync=None) -> None:
@@ -614,7 +643,7 @@ class ConvBN:
 
     # ---- backward -------------------------------------------------------------------------------
     def backward(self, dout: Optional[Act], sink: GradSink, training: bool, se: Optional["SEState"], dx: Optional[Act],
-                 outc_grad=None, pool_grad=None) -> None:
+                 outc_grad=None, pool_grad=None, bstat_for: Optional["ConvBN"] = None, bstat_se: bool = False) -> None:
         """dout: gradient wrt this unit's output (after ReLU and, if `se`, the SE gate); or `outc_grad` =
         (dlogits, outc weight, K) when this unit feeds the 1x1 output conv: the reduce and apply passes then recompute
         that gradient from dlogits instead of reading a 64-channel tensor (csrc/pointwise.hip, OutcGrad)."""
@@ -634,8 +663,12 @@ class ConvBN:
             dpool, parg = pool_grad
             call("insar_bnrelu_bwd_reduce_pool", dout.ref, dpool.ref, ptr(parg), self.y.ref, ptr(self.scale), ptr(self.shift),
                  ptr(self.red_part), 1, self.red_rpp, s)
+        elif self.bred_ready:
+            pass                  # the sums came out of the epilogue of the GEMM that wrote dout (bstat_slab)
         else:
             call("insar_bnrelu_bwd_reduce", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.red_part), 1, self.red_rpp, s)
+        red, red_rows = (self.bred, self.bred_rows) if (self.bred_ready and outc_grad is None and pool_grad is None) else (self.red_part, self.red_rows)
+        self.bred_ready = False
         d = InsarBnSeBwd()
         d.B, d.H, d.W, d.C = B, H, W, self.cout
         d.Cr = se.cr if se else 1
@@ -650,7 +683,7 @@ class ConvBN:
         d.k1, d.k2 = ptr(self.k1), ptr(self.k2)
         d.accumulate = 0
         dbias = ptr(sink.view(self.conv.bias)) if self.conv.bias is not None else 0
-        coef_args = (C.byref(d), ptr(self.red_part), self.red_rows, ptr(self.scale), ptr(self.shift), ptr(self.bwd_ws),
+        coef_args = (C.byref(d), ptr(red), red_rows, ptr(self.scale), ptr(self.shift), ptr(self.bwd_ws),
                      dbias, int(training))
         # Training mode: only the per-image stage stays on the dgrad chain; the apply pass folds k1 / k2 from its
         # partial sums itself and the batch fold (parameter gradients) follows the weight gradient on the side stream.
@@ -706,15 +739,48 @@ class ConvBN:
             if self.small:
                 raise _lib.InsarError(f"{self.name}: input gradient of the direct first-layer conv is not provided")
             if self.c64_bwd:
-                _conv3x3_c64(self.dy, dx, self.w.dgrad(), 1, None)
-            elif self.c64:
-                _igemm(self.dy, dx, self.w.dgrad(), self.cin, H, W, 1, _TAPS3_DGRAD, 0)
-            elif self.flat_bwd:
-                _conv3x3_flat(self.dy, dx, self.w.dgrad(), 1, None)
+                slab = None
+                if bstat_for is not None and BSTAT_FUSE and not bstat_se and _same_layout(dx, bstat_for.y):
+                    slab = bstat_for.bstat_slab(call("insar_conv3x3_c64_rows", self.dy.ref), False)
+                if slab:
+                    _conv3x3_c64(self.dy, dx, self.w.dgrad(), 1, slab[0], bstat=slab[1])
+                    bstat_for.bred_ready = True
+                else:
+                    _conv3x3_c64(self.dy, dx, self.w.dgrad(), 1, None)
+            elif self.flat_bwd and not self.c64:
+                slab = None
+                if bstat_for is not None and BSTAT_FUSE and not bstat_se and _same_layout(dx, bstat_for.y):
+                    slab = bstat_for.bstat_slab(call("insar_conv3x3_flat_stat_rows", self.dy.ref, self.cin, 4 if _flat_persist(1) else 0), False)
+                if slab:
+                    _conv3x3_flat(self.dy, dx, self.w.dgrad(), 1, slab[0], bstat=slab[1])
+                    bstat_for.bred_ready = True
+                else:
+                    _conv3x3_flat(self.dy, dx, self.w.dgrad(), 1, None)
             else:
-                _igemm(self.dy, dx, self.w.dgrad(), self.cin, H, W, 1, _TAPS3_DGRAD, 0)
+                slab = _igemm_bstat_slab(bstat_for, bstat_se, self.M, self.cin, H * W, dx)
+                _igemm(self.dy, dx, self.w.dgrad(), self.cin, H, W, 1, _TAPS3_DGRAD, 0,
+                       stats=slab[0] if slab else None, bstat=slab[1] if slab else None)
+                if slab:
+                    bstat_for.bred_ready = True
         if WGRAD_LATE:
             weight_grad()
+
+
+def _same_layout(a: Act, b: Act) -> bool:
+    return (a.buf.shape == b.buf.shape and a.buf.dtype == b.buf.dtype and a.C == b.C and a.c_off == b.c_off
+            and a.c_len == b.c_len)
+
+
+def _igemm_bstat_slab(consumer: Optional["ConvBN"], se: bool, M: int, N: int, hw: int, out: Act):
+    """Statistics slab + InsarBstat operands for an insar_igemm launch (mode 0, dense output `out`, M rows, N columns) whose
+    output is `consumer`'s incoming gradient, or None: BSTAT_FUSE off, layouts differ, or — for a unit with an SE gate,
+    whose coefficient stage needs the sums per image — GEMM row tiles that straddle images."""
+    if consumer is None or not BSTAT_FUSE or not _same_layout(out, consumer.y):
+        return None
+    bm = call("insar_igemm_tile_rows", M, N)
+    if se and hw % bm:
+        return None
+    return consumer.bstat_slab(call("insar_igemm_num_mtiles", M, N), se)
 
 
 def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
@@ -829,7 +895,7 @@ class DoubleConvPlan:
                  pool_grad=None) -> None:
         if self.dz1 is None:
             self.dz1 = Act.alloc(self.x.B, self.x.H, self.x.W, self.u1.cout, self.ctx.dtype, self.ctx.device)
-        self.u2.backward(dout, sink, training, self.se, self.dz1, outc_grad, pool_grad)
+        self.u2.backward(dout, sink, training, self.se, self.dz1, outc_grad, pool_grad, bstat_for=self.u1)
         self.u1.backward(self.dz1, sink, training, None, dx)
 
 
@@ -866,8 +932,9 @@ class UpPlan:
         if self.resize:
             call("insar_resize_bilinear_fwd", self.conv_out.ref, self.out.ref, _lib.stream_ptr())
 
-    def backward(self, dout: Act, sink: GradSink, dx: Optional[Act]) -> None:
-        """dout: gradient slice wrt this layer's output (upper half of the dcat buffer)."""
+    def backward(self, dout: Act, sink: GradSink, dx: Optional[Act], consumer: Optional["DoubleConvPlan"] = None) -> None:
+        """dout: gradient slice wrt this layer's output (upper half of the dcat buffer). consumer: the block whose output
+        this layer's input is — its last unit takes its BatchNorm-backward sums from the epilogue of the input-gradient GEMM."""
         ctx, s = self.ctx, _lib.stream_ptr()
         x, B, h, w = self.x, self.x.B, self.x.H, self.x.W
         if self.resize:              # gradient of the (2h, 2w) conv output = adjoint of the bilinear resize
@@ -904,7 +971,12 @@ class UpPlan:
         if not WGRAD_LATE:
             weight_grad()
         if dx is not None:
-            _igemm(dout, dx, self.w.dgrad(), self.cin, h, w, 2, _TAPS2, 0)
+            unit = consumer.u2 if (consumer is not None and consumer.pool_arg is None) else None
+            slab = _igemm_bstat_slab(unit, consumer is not None and consumer.se is not None, B * h * w, self.cin, h * w, dx)
+            _igemm(dout, dx, self.w.dgrad(), self.cin, h, w, 2, _TAPS2, 0,
+                   stats=slab[0] if slab else None, bstat=slab[1] if slab else None)
+            if slab:
+                unit.bred_ready = True
         if WGRAD_LATE:
             weight_grad()
 
@@ -1134,7 +1206,7 @@ class UNetPlan:
             if og and wg:
                 self.outc.fold_fused(sink)
             dsrc = self.dx5 if i == 0 else self.ddec[l + 1]
-            self.up[i].backward(self.dcat[l].slice(w[l], w[l]), sink, dsrc)
+            self.up[i].backward(self.dcat[l].slice(w[l], w[l]), sink, dsrc, self.enc[4] if i == 0 else self.dconv[i - 1])
             if on_bucket is not None:
                 on_bucket(self, ("dec", i))
         for l in (4, 3, 2, 1, 0):

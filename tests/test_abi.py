@@ -39,7 +39,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 def test_struct_layouts_match_the_c_compiler(tmp_path):
     structs = {"InsarAct": _lib.InsarAct, "InsarIgemm": _lib.InsarIgemm, "InsarWgrad": _lib.InsarWgrad,
                "InsarBnFinalize": _lib.InsarBnFinalize, "InsarSeFwd": _lib.InsarSeFwd, "InsarBnSeBwd": _lib.InsarBnSeBwd,
-               "InsarCam": _lib.InsarCam}
+               "InsarCam": _lib.InsarCam, "InsarBstat": _lib.InsarBstat}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, st in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
