@@ -73,54 +73,14 @@ def cpu_baseline(size: int = 256):
                       f"tile (config 1); torch {torch.__version__} CPU/oneDNN, {cores} threads"}
 
 
-def main() -> int:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="tiles per GPU (config 2: 16)")
-    ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--loss", default=None, choices=["dice_ce", "ce"], help="default: dice_ce for unet (config 2), ce for deeplab")
-    ap.add_argument("--model", default="unet", choices=["unet", "deeplab"],
-                    help="unet = U-Net-CA (configs 2-4, the headline metric); deeplab = DeepLabV3-CA (config 5, 1-channel tiles)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
-    ap.add_argument("--shard-optimizer", action="store_true",
-                    help="N > 1: reduce-scatter + Adam on the 1/N shard + all-gather instead of all-reduce + full Adam")
-    ap.add_argument("--graph", default="off", choices=["auto", "on", "off"],
-                    help="replay the step from a captured hipGraph (insar_unet_ca_amd.GraphedTrainStep): off by default (measured slower than eager launches on ROCm 7.2: 8.6 vs 7.9 ms/step); auto = on for 1 GPU, off "
-                         "under data parallelism (the RCCL collectives inside backward are issued eagerly)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timing", action="store_true")
-    args = ap.parse_args()
+def _traffic_files():
+    import glob
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
-    ndev = torch.cuda.device_count()
-    if world > ndev and args.backend == "nccl":
-        # one process per GPU over RCCL: folding ranks onto one device would silently measure something else
-        print(f"error: WORLD_SIZE={world} but only {ndev} GPU(s) visible; RCCL needs one device per rank "
-              "(use --backend gloo for a functional rehearsal on fewer GPUs)", file=sys.stderr)
-        return 2
-    local_rank = local_rank % max(ndev, 1)          # gloo rehearsal only: several ranks may share the one visible GPU
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
-    import torch.distributed as dist
-
-    import insar_unet_ca_amd as iu
-    from insar_unet_ca_amd import engine
-    from insar_unet_ca_amd.data import make_batch
-
-    if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(args.backend)
-
+def measure(args, world: int, rank: int, dev, dist, iu, engine, make_batch):
+    """One configuration: build the model, warm up, time args.steps steps (barrier + synchronize on both sides, max over
+    ranks), then the two per-kernel event passes. Returns the result dict on rank 0 (None elsewhere)."""
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     if args.loss is None:
         args.loss = "dice_ce" if args.model == "unet" else "ce"
@@ -133,11 +93,12 @@ def main() -> int:
     model = net
     if world > 1:
         from insar_unet_ca_amd.parallel import DataParallel
-        model = DataParallel(net, shard_optimizer=args.shard_optimizer)
+        model = DataParallel(net, shard_optimizer=args.shard_optimizer, bucket_mb=args.bucket_mb)
+        model.record_exposed = True            # HIP events around the wait for the gradient exchange (exposed_comm_ms)
     crit = iu.DiceCELoss(ignore_index=255) if args.loss == "dice_ce" else iu.CrossEntropyLoss(ignore_index=255)
     if world > 1 and args.shard_optimizer:
         from insar_unet_ca_amd.parallel import ShardedAdam
-        opt = ShardedAdam(model, lr=1e-4)
+        opt = ShardedAdam(model, lr=1e-4, defer_gather=True)
     else:
         opt = iu.Adam(net.parameters(), lr=1e-4)
 
@@ -148,8 +109,31 @@ def main() -> int:
         x, y = make_batch((rank * nb + b) * args.batch, args.batch, args.size, channels=channels)
         batches.append((x.to(dev), y.to(dev)))
 
+    feed = None
+    if args.stream_input:
+        # the reference's loop copies every batch from the pinned-memory loader inside the step (:339-340, :436-451); here
+        # the host batches (pinned, the same two tiles sets over and over) go through data.DevicePrefetcher: batch i+1 is
+        # copied on a copy stream while step i computes. 17 MB of H2D per step at config 2.
+        from insar_unet_ca_amd.data import DevicePrefetcher
+
+        class _Cycle:
+            def __init__(self, items):
+                self.items = items
+
+            def __len__(self):
+                return 1 << 30
+
+            def __iter__(self):
+                i = 0
+                while True:
+                    yield self.items[i % len(self.items)]
+                    i += 1
+
+        host = [(x.cpu().pin_memory(), y.cpu().pin_memory()) for x, y in batches]
+        feed = iter(DevicePrefetcher(_Cycle(host), dev))
+
     def step(i: int):
-        x, y = batches[i % nb]
+        x, y = next(feed) if feed is not None else batches[i % nb]
         opt.zero_grad(set_to_none=True)
         loss = crit(model(x), y)
         loss.backward()
@@ -161,6 +145,9 @@ def main() -> int:
     use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
     if use_graph and world > 1:
         print("error: --graph on is not available under data parallelism", file=sys.stderr)
+        return 2
+    if use_graph and args.stream_input:
+        print("error: --stream-input feeds the eager step (the graphed step copies into its own static inputs)", file=sys.stderr)
         return 2
     for i in range(args.warmup):
         step(i)
@@ -179,6 +166,7 @@ def main() -> int:
 
     if world > 1:
         dist.barrier()
+        model.exposed_events.clear()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -188,10 +176,22 @@ def main() -> int:
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    dp_info = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ev = model.exposed_events
+        exposed = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+        t = torch.tensor([exposed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dp_info = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(),
+                   "exchange": "reduce_scatter+sharded_adam+all_gather" if args.shard_optimizer else "allreduce",
+                   "bucket_mb": args.bucket_mb, "buckets": len(model.sharded.bounds) if model.sharded is not None else None,
+                   # max over ranks of the mean time the main stream sat waiting for the gradient exchange after the last
+                   # backward kernel (HIP events around DataParallel's wait; 0 = fully overlapped with backward)
+                   "exposed_comm_ms": round(float(t.item()), 3)}
+        model.record_exposed = False
 
     # Roofline leg: the same K steps twice more, in the same process, with a HIP-event pair around every GEMM-class
     # launch, recorded on the stream the kernel is launched on (main or side). Pass 1 keeps the launch configuration
@@ -239,10 +239,12 @@ def main() -> int:
             "config": {"workload": f"{name} {args.dtype}, batch {args.batch}x{channels}x{args.size}x{args.size} "
                                    f"per GPU, {'Dice+CE' if args.loss == 'dice_ce' else 'CE'} + Adam(lr=1e-4) training on synthetic InSAR tiles",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
-            "final_loss": round(final_loss, 5), "hipgraph": bool(use_graph),
+            "final_loss": round(final_loss, 5), "hipgraph": bool(use_graph), "input": "streamed from pinned host memory (copy stream, one batch ahead)" if args.stream_input else "resident in HBM",
             "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 3),
             "hbm_allocated_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
         }
+        if dp_info is not None:
+            out.update(dp_info)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         per_param = 36 if args.dtype == "bf16" else 40      # weights fwd + bwd, gradient write, Adam
         bytes_tile = (act_bytes + per_param * nparams / args.batch) if act_bytes is not None else 0.0
@@ -257,6 +259,21 @@ def main() -> int:
                                 "algorithmic": (f"{flop_tile / 1e9:.1f} GFLOP and {bytes_tile / 1e6:.0f} MB per tile (SURVEY 8d)" if act_bytes is not None
                                                 else f"{flop_tile / 1e9:.1f} GFLOP per tile (layer shapes of the plan; no byte model)")
                                                + ", whole step incl. loss and Adam, timed region"}
+        if args.model == "unet" and args.dtype == "bf16" and args.size == 256 and args.batch == 16:
+            # whole-step HBM traffic from the PMC passes of this configuration (tools/pmc_traffic.py: every dispatch between
+            # two Adam launches), next to the algorithmic bytes of the byte model
+            for tpath in _traffic_files():
+                try:
+                    st = json.load(open(tpath)).get("__step__")
+                except Exception:
+                    st = None
+                if st:
+                    alg = bytes_tile * args.batch
+                    out["roofline_step"]["traffic"] = st["hbm_bytes_per_step"]
+                    out["roofline_step"]["algorithmic_bytes_per_step"] = round(alg)
+                    out["roofline_step"]["traffic_over_algorithmic"] = round(st["hbm_bytes_per_step"] / alg, 3)
+                    out["roofline_step"]["traffic_source"] = os.path.relpath(tpath, ROOT)
+                    break
         if act_bytes is None:
             out.pop("frac_of_hbm_roofline")
         if timers:
@@ -266,20 +283,24 @@ def main() -> int:
             dom_tag = max(summ, key=lambda k: summ[k]["ms"]) if summ else None
             if dom_tag:
                 dom = summ[dom_tag]
-                traffic, tfile = None, None
-                import glob
-                for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+                traffic, tfile, tconf = None, None, None
+                for tpath in _traffic_files():
                     try:
-                        traffic = json.load(open(tpath)).get(dom_tag, {}).get("hbm_bytes_per_launch")
+                        tj = json.load(open(tpath))
                     except Exception:
-                        traffic = None
-                    if traffic is not None:
+                        continue
+                    stem = dom_tag.rstrip(">")          # the profiler's name carries further template arguments
+                    hit = [v for k, v in tj.items() if k.startswith(stem) and isinstance(v, dict) and "hbm_bytes_per_launch" in v]
+                    if hit:
+                        traffic = hit[0]["hbm_bytes_per_launch"]
                         tfile = os.path.relpath(tpath, ROOT)
+                        tconf = tj.get("__config__", {}).get("launch_configuration")
                         break
                 al = alone.get(dom_tag)
                 out["roofline"] = {
                     "kernel": dom_tag, "bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": traffic,
+                    "traffic_launch_configuration": tconf,
                     "flop_per_launch": round(dom["flops"] / dom["launches"], 1),
                     "algorithmic_bytes_per_launch": round(dom.get("bytes", 0.0) / dom["launches"], 1) or None,
                     "avg_launch_us": round(dom["avg_us"], 2), "launches": dom["launches"],
@@ -292,7 +313,8 @@ def main() -> int:
                                 "overlap share the chip, so their durations are longer than alone; %.2f ms/step with "
                                 "events vs %.2f ms/step timed); `alone` = a third pass on ONE stream, every kernel by "
                                 "itself on the chip (%.2f ms/step); compare profiles/ kernel stats; traffic = rocprofv3 "
-                                "PMC (2*FETCH_SIZE + WRITE_SIZE) per launch from %s" %
+                                "PMC (2*FETCH_SIZE + WRITE_SIZE) per launch from %s, taken in the launch configuration named "
+                                "by traffic_launch_configuration (algorithmic_bytes_per_launch is the timed configuration's)" %
                                 (args.steps, 1e3 * t_el / args.steps, ms,
                                  1e3 * timers["alone"].elapsed / args.steps, tfile or "profiles/ (none found)"),
                 }
@@ -311,6 +333,94 @@ def main() -> int:
             out["gemm_total"] = total(summ, t_el)
             out["gemm_kernels_alone"] = table(alone, timers["alone"].elapsed)
             out["gemm_total_alone"] = total(alone, timers["alone"].elapsed)
+        return out
+    return None
+
+
+def other_configs(args, dev, dist, iu, engine, make_batch) -> dict:
+    """Configs 4 and 5 of BASELINE.json for the same number of steps, in the same process, so that the driver's one bench
+    line records them beside the headline (config 2). Same timed-region rules (measure()); no per-kernel event passes."""
+    import copy
+    import gc
+    res = {}
+    for key, over in (("config4_unet_fp32_512_b8_ce", dict(dtype="f32", size=512, batch=8, loss="ce", model="unet")),
+                      ("config5_deeplabv3_ca_bf16_256_b16_ce", dict(dtype="bf16", size=256, batch=16, loss="ce", model="deeplab"))):
+        a = copy.copy(args)
+        for k, v in over.items():
+            setattr(a, k, v)
+        a.no_kernel_timing, a.graph, a.stream_input = True, "off", False
+        gc.collect()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats(dev)
+        r = measure(a, 1, 0, dev, dist, iu, engine, make_batch)
+        res[key] = ({k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline_step",
+                                       "host_enqueue_ms_per_step", "hbm_allocated_gb", "final_loss") if k in r}
+                    if isinstance(r, dict) else {"error": f"measure() returned {r!r}"})
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="tiles per GPU (config 2: 16)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--loss", default=None, choices=["dice_ce", "ce"], help="default: dice_ce for unet (config 2), ce for deeplab")
+    ap.add_argument("--model", default="unet", choices=["unet", "deeplab"],
+                    help="unet = U-Net-CA (configs 2-4, the headline metric); deeplab = DeepLabV3-CA (config 5, 1-channel tiles)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--shard-optimizer", action="store_true",
+                    help="N > 1: reduce-scatter + Adam on the 1/N shard + all-gather instead of all-reduce + full Adam")
+    ap.add_argument("--graph", default="off", choices=["auto", "on", "off"],
+                    help="replay the step from a captured hipGraph (insar_unet_ca_amd.GraphedTrainStep): off by default (measured slower than eager launches on ROCm 7.2: 8.6 vs 7.9 ms/step); auto = on for 1 GPU, off "
+                         "under data parallelism (the RCCL collectives inside backward are issued eagerly)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip configs 4 and 5 (the default 1-GPU run of config 2 reports them under `other_configs`)")
+    ap.add_argument("--bucket-mb", type=float, default=16.0, help="N > 1: minimum size of a gradient-exchange bucket (MiB)")
+    ap.add_argument("--stream-input", action="store_true",
+                    help="feed every step from the host: batches in pinned memory, copied on a copy stream while the previous "
+                         "step computes (the reference copies per step, Unet-ChannalAttention.py:339-340)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
+    ndev = torch.cuda.device_count()
+    if world > ndev and args.backend == "nccl":
+        # one process per GPU over RCCL: folding ranks onto one device would silently measure something else
+        print(f"error: WORLD_SIZE={world} but only {ndev} GPU(s) visible; RCCL needs one device per rank "
+              "(use --backend gloo for a functional rehearsal on fewer GPUs)", file=sys.stderr)
+        return 2
+    local_rank = local_rank % max(ndev, 1)          # gloo rehearsal only: several ranks may share the one visible GPU
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd import engine
+    from insar_unet_ca_amd.data import make_batch
+
+    if world > 1:
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+
+    out = measure(args, world, rank, dev, dist, iu, engine, make_batch)
+    if isinstance(out, int):
+        return out
+    if rank == 0 and isinstance(out, dict):
+        if world == 1 and not args.no_other_configs and args.model == "unet" and args.dtype == "bf16" and args.size == 256:
+            out["other_configs"] = other_configs(args, dev, dist, iu, engine, make_batch)
         if world == 1 and not args.no_cpu_baseline and args.model == "unet":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -68,6 +68,20 @@ struct FlatCfg {
   static constexpr int LDS_BYTES = MAIN + ROWINFO + STATB;
 };
 
+// Diagnostic build only (-DINSAR_STAMPS, tools/stamp_flat.py): s_memtime stamps of the phases of a tile, summed per
+// work-group by wave 0; the product library contains none of this.
+#ifdef INSAR_STAMPS
+__device__ unsigned long long g_flat_stamps[1024 * 8];
+#define FL_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_acc[k] += now_ - stamp_prev; stamp_prev = now_; } while (0)
+extern "C" int insar_debug_flat_stamps(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_flat_stamps), sizeof(g_flat_stamps)) != hipSuccess) return -1;
+  if (reset) { static unsigned long long z[1024 * 8]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_flat_stamps), z, sizeof(z)) != hipSuccess) return -2; }
+  return 0;
+}
+#else
+#define FL_STAMP(k)
+#endif
+
 template <int N>
 __device__ __forceinline__ void fl_wait_and_barrier() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");   // lgkmcnt: see common.h, dma_drain_and_barrier
@@ -101,7 +115,12 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
   float cs1[CHc], cs2[CHc];
 #pragma unroll
   for (int j = 0; j < CHc; ++j) { cs1[j] = 0.f; cs2[j] = 0.f; }
+#ifdef INSAR_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // wave-uniform (scalar registers)
+  unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
   for (int vb = blockIdx.x; vb < a.total_tiles; vb += gridDim.x) {
+  FL_STAMP(7);          // loop turn-around (+ kernel start for the first tile)
   int t;
   {
     const int nwg = a.total_tiles, bid = vb;
@@ -179,11 +198,15 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
   if constexpr (PP) {
     static_assert(sizeof(T) == 2, "ping-pong loop: bf16");
     const int grp = wave >> 2;
+    FL_STAMP(0);        // tile geometry
     stageA(0, 0, 0);
     stageB(0, 0, 0);
     stageB(1, 0, 1);
+    FL_STAMP(1);        // issue of the first slabs
     fill_row_out();
+    FL_STAMP(2);        // output row offsets
     fl_wait_and_barrier<0>();           // everything landed; rowOut visible
+    FL_STAMP(3);        // first slabs landed
     if (grp == 1) __builtin_amdgcn_s_barrier();                 // group 1 runs one barrier behind
     for (int kc = 0; kc < kcs; ++kc) {
 #pragma unroll
@@ -299,6 +322,7 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
   }
   }
   __syncthreads();
+  FL_STAMP(4);          // K loop
 
   // ---- epilogue (as igemm.hip): registers -> LDS tile -> 16-byte NHWC stores + BN partial sums ------
   char* tile = smem;
@@ -400,7 +424,9 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
       a.stats[((long long)mtile * 2 + 1) * a.N + n0 + tid] = v2;
     }
   }
+  FL_STAMP(5);          // epilogue: transpose through LDS, stores, statistics
   __syncthreads();          // the next tile's LDS-DMA rewrites the ring the epilogue tile aliases
+  FL_STAMP(6);          // the other waves' epilogues
   }
   if (a.stats && a.carry) {
     constexpr int CPR = BN * ES / 16;
@@ -426,6 +452,12 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
       a.stats[((long long)blockIdx.x * 2 + 1) * a.N + tid] = v2;
     }
   }
+#ifdef INSAR_STAMPS
+  if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_flat_stamps[(blockIdx.x & 1023) * 8 + k], stamp_acc[k]);
+  }
+#endif
 }
 
 // ---- host side -----------------------------------------------------------------------------------

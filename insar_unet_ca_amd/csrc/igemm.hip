@@ -83,6 +83,19 @@ struct IgemmCfg {
   static constexpr int LDS_BYTES = MAIN + ROWINFO + STATB + TAPB;
 };
 
+// Diagnostic build only (-DINSAR_STAMPS, tools/stamp_igemm.py): s_memtime stamps of the phases of a work-group
+#ifdef INSAR_STAMPS
+__device__ unsigned long long g_igemm_stamps[1024 * 8];
+#define IG_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_acc[k] += now_ - stamp_prev; stamp_prev = now_; } while (0)
+extern "C" int insar_debug_igemm_stamps(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_igemm_stamps), sizeof(g_igemm_stamps)) != hipSuccess) return -1;
+  if (reset) { static unsigned long long z[1024 * 8]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_igemm_stamps), z, sizeof(z)) != hipSuccess) return -2; }
+  return 0;
+}
+#else
+#define IG_STAMP(k)
+#endif
+
 // drain the LDS-DMA queue down to N outstanding per wave, then meet the other waves
 template <int N>
 __device__ __forceinline__ void dma_wait_and_barrier() {
@@ -115,6 +128,11 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
   int* stap = (int*)(smem + Cfg::MAIN + Cfg::ROWINFO + Cfg::STATB);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef INSAR_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+  const unsigned long long stamp_t0 = stamp_prev, stamp_r0 = __builtin_amdgcn_s_memrealtime();   // [6] / [7]: shader clock vs 100 MHz
+#endif
   // XCD-aware tile order: blocks that share an XCD (blockIdx % 8) get consecutive tiles, so the
   // A rows / halo rows shared by neighbouring tiles hit in that XCD's L2 (bijective remap).
   int t;
@@ -150,6 +168,7 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
     rowHW[tid] = valid ? (((ho * a.stride + 1) << 16) | (wo * a.stride + 1)) : (0x4000 << 16);
   }
   __syncthreads();
+  IG_STAMP(0);          // row tables
 
   // per-thread staging geometry: chunk q = i*THREADS + tid -> LDS row q>>3, lane-linear position q&7
   constexpr int RPI = THREADS / 8;                  // rows covered by one DMA instruction of the block
@@ -229,6 +248,7 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    IG_STAMP(1);        // first slab landed
     if (grp == 1) __builtin_amdgcn_s_barrier();                   // group 1 runs one barrier behind
     {
     // two phases per K tile: pixel half 0, then pixel half 1 of the wave's 64 pixels, each against all of the wave's BN/2
@@ -298,6 +318,7 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
     if (p < nk) stage(p, p);
   if (nk >= NSTAGE - 1) dma_wait_and_barrier<(NSTAGE - 2) * PER>();
   else dma_wait_and_barrier<0>();
+  IG_STAMP(1);          // first slab landed
   int buf = 0, pbuf = NSTAGE - 1;                   // pbuf = ring slot the next prefetch goes to
   for (int ks = 0; ks < nk; ++ks) {
     const bool more = ks + NSTAGE - 1 < nk;
@@ -326,6 +347,7 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
   }
   }
   __syncthreads();
+  IG_STAMP(2);          // K loop
 
   // ---- epilogue: registers -> LDS tile [pixel][channel] -> 16-byte NHWC stores (+stats) ----------
   char* tile = smem;
@@ -347,6 +369,7 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
     }
   __syncthreads();
 
+  IG_STAMP(3);          // accumulators -> LDS tile
   constexpr int CPR = BN * ES / 16;               // 16-byte chunks per tile row
   constexpr int ITER = BM * CPR / THREADS;
   constexpr int RSTEP = THREADS / CPR;
@@ -408,6 +431,7 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
       *(uint4*)(a.y + (ro + col_off) * ES) = Chunk<T>::pack(f);
     }
   }
+  IG_STAMP(4);          // stores (+ sums)
   if (a.stats) {
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
@@ -435,6 +459,14 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
       a.stats[((long long)mtile * 2 + 1) * a.N + n0 + tid] = v2;
     }
   }
+#ifdef INSAR_STAMPS
+  IG_STAMP(5);          // statistics fold
+  stamp_acc[6] = stamp_prev - stamp_t0; stamp_acc[7] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+  if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_igemm_stamps[(blockIdx.x & 1023) * 8 + k], stamp_acc[k]);
+  }
+#endif
 }
 
 // Tile selection: the 256-row / 8-wave / 3-slab-ring variant needs enough tiles to fill 256 CUs: 256 x 128

@@ -44,6 +44,19 @@ __device__ __forceinline__ int w3_swz(int row) {
   else return ((row >> 1) & 3) << 1;
 }
 
+// Diagnostic build only (-DINSAR_STAMPS, tools/stamp_gemm.py)
+#ifdef INSAR_STAMPS
+__device__ unsigned long long g_wgrad3_stamps[1024 * 8];
+#define W3_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_acc[k] += now_ - stamp_prev; stamp_prev = now_; } while (0)
+extern "C" int insar_debug_wgrad3_stamps(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgrad3_stamps), sizeof(g_wgrad3_stamps)) != hipSuccess) return -1;
+  if (reset) { static unsigned long long z[1024 * 8]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad3_stamps), z, sizeof(z)) != hipSuccess) return -2; }
+  return 0;
+}
+#else
+#define W3_STAMP(k)
+#endif
+
 template <typename T, int TM, int TN, int NW>
 struct Wgrad3Cfg {
   static constexpr int ES = sizeof(T);
@@ -70,6 +83,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad3_kernel(Wgra
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef INSAR_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
   int t;
   {
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -161,8 +178,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad3_kernel(Wgra
   const int r16 = lane & 15, kq = lane >> 4;
 
   if (ks0 < ks1) {
+    W3_STAMP(0);        // set-up
     stage(0, next_pixel());
     dma_drain_and_barrier();
+    W3_STAMP(1);        // first step landed
     for (int ks = ks0; ks < ks1; ++ks) {
       const int buf = (ks - ks0) & 1;
       if (ks + 1 < ks1) stage(buf ^ 1, next_pixel());
@@ -286,6 +305,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad3_kernel(Wgra
     }
   }
 
+  W3_STAMP(2);          // K loop
   if constexpr (MF == 32) {
     // C layout of a 32x32 accumulator: col (co) = lane & 31, row (ci) = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
 #pragma unroll
@@ -316,6 +336,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void wgrad3_kernel(Wgra
         *(f32x4_t*)(out + (long long)co * a.Cin + ci) = acc[t3][mt][nt];
       }
   }
+#ifdef INSAR_STAMPS
+  W3_STAMP(3);          // slab stores
+  if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_wgrad3_stamps[(blockIdx.x & 1023) * 8 + k], stamp_acc[k]);
+  }
+#endif
 }
 
 template <typename T, int TM, int TN, int NW, int MF = 16>

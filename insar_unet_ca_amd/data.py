@@ -212,3 +212,80 @@ class SeededBatches:
         order = self.rng.permutation(len(self.batches)) if self.shuffle else np.arange(len(self.batches))
         for i in order:
             yield self.batches[int(i)]
+
+
+class DevicePrefetcher:
+    """Feeds a training loop from a host loader without stalling the step: the reference copies every
+    batch inside the step (`imgs.to(device)`, Unet-ChannalAttention.py:339-340, from the pinned-memory DataLoader of
+    :436-451); here batch i+1 is copied on a COPY STREAM (pinned source, non_blocking) while step i computes, into one of
+    two device slots, and the compute stream only waits for the copy's event. Iterating yields (images, masks) device
+    tensors. A slot is refilled only after the step that used it has been enqueued (`record_stream`-free: the consumer's
+    position on the compute stream is recorded as an event when the NEXT batch is requested and the copy stream waits for
+    it), so the copy of batch i+2 never overwrites tensors that step i still reads.
+
+    `loader`: any iterable of (images, masks) CPU tensors (make_loader(...), SeededBatches, a list). Tensors that are not
+    pinned are staged through this object's own pinned buffers."""
+
+    def __init__(self, loader, device, slots: int = 2):
+        self.loader, self.device = loader, torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("DevicePrefetcher needs a ROCm device (there is no CPU fallback on the HIP path)")
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.nslots = max(2, slots)
+        self._dev = [None] * self.nslots
+        self._pin = [None] * self.nslots
+        self._free = [None] * self.nslots          # event: the step that last used this slot has been enqueued
+        self._ready = [None] * self.nslots         # event: the last copy into this slot (out of its pinned buffer) is done
+        self.dataset = getattr(loader, "dataset", None)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, slot: int, batch):
+        x, y = batch
+        if self._dev[slot] is None or self._dev[slot][0].shape != x.shape or self._dev[slot][1].shape != y.shape:
+            self._dev[slot] = (torch.empty(x.shape, dtype=x.dtype, device=self.device),
+                               torch.empty(y.shape, dtype=y.dtype, device=self.device))
+            self._pin[slot] = None
+        src = []
+        for k, t in enumerate((x, y)):
+            if not t.is_pinned():
+                if self._pin[slot] is None:
+                    self._pin[slot] = [torch.empty(x.shape, dtype=x.dtype).pin_memory(), torch.empty(y.shape, dtype=y.dtype).pin_memory()]
+                if self._ready[slot] is not None:
+                    self._ready[slot].synchronize()   # the previous copy OUT of this pinned buffer (two batches ago) is done
+                self._pin[slot][k].copy_(t)
+                t = self._pin[slot][k]
+            src.append(t)
+        with torch.cuda.stream(self.copy_stream):
+            if self._free[slot] is not None:
+                self.copy_stream.wait_event(self._free[slot])
+            self._dev[slot][0].copy_(src[0], non_blocking=True)
+            self._dev[slot][1].copy_(src[1], non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self.copy_stream)
+        self._ready[slot] = ready
+        return ready
+
+    def __iter__(self):
+        it = iter(self.loader)
+        pending = []                                 # (slot, ready event)
+        slot = 0
+        try:
+            pending.append((slot, self._stage(slot, next(it))))
+        except StopIteration:
+            return
+        while pending:
+            cur, ready = pending.pop(0)
+            nxt = (cur + 1) % self.nslots
+            try:
+                batch = next(it)
+            except StopIteration:
+                batch = None
+            if batch is not None:
+                pending.append((nxt, self._stage(nxt, batch)))
+            torch.cuda.current_stream(self.device).wait_event(ready)
+            yield self._dev[cur]
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(self.device))       # the consumer's launches are enqueued up to here
+            self._free[cur] = done

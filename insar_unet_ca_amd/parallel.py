@@ -155,6 +155,8 @@ class DataParallel(torch.nn.Module):
         self.sharded: Optional[ShardedBuckets] = None
         self.flat_p: Optional[torch.Tensor] = None
         self._gathers: List = []
+        self.record_exposed = False            # bench.py: HIP events around the wait for the gradient exchange
+        self.exposed_events: List = []
         if shard_optimizer:
             self._flatten_parameters()
         module._hooks["on_begin"] = self._on_begin
@@ -268,7 +270,15 @@ class DataParallel(torch.nn.Module):
         if self._begin < total:
             plan.ctx.join_side()
             self._exchange(plan, self._begin, total)
-        self.reducer.finish()
+        if self.record_exposed and plan.sink.flat().is_cuda:
+            # from the end of backward's own kernels on the main stream to the point where the reduced gradients are usable
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.reducer.finish()
+            e1.record()
+            self.exposed_events.append((e0, e1))
+        else:
+            self.reducer.finish()
         self._stage = self._begin = self._bucket = 0
 
 

@@ -15,23 +15,23 @@ echo "== bench"; timeout -k 10 400 python3 "$R/bench.py" > "$OUT/bench.json" 2> 
 cut -c1-330 "$OUT/bench.json"
 echo "== phase times"; timeout -k 10 100 python3 "$R/tools/phase_times.py" 2>/dev/null | tee "$OUT/phase_times.log"
 echo "== rocprof stats (default command: timed region on two streams + the two event passes)"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/p1" -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/p1.log" 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/p1" -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs > "$OUT/p1.log" 2>&1 || exit 1
 echo "== rocprof stats (timed region only, two streams)"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/p3" -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing > "$OUT/p3.log" 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/p3" -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/p3.log" 2>&1 || exit 1
 echo "== rocprof stats (single stream)"
-INSAR_SIDE_STREAM=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/p2" -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing > "$OUT/p2.log" 2>&1 || exit 1
-echo "== PMC passes (single stream: every kernel alone on the chip)"
-INSAR_SIDE_STREAM=0 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pF" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing > "$OUT/pF.log" 2>&1 || exit 1
-INSAR_SIDE_STREAM=0 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pW" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing > "$OUT/pW.log" 2>&1 || exit 1
+INSAR_SIDE_STREAM=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/p2" -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/p2.log" 2>&1 || exit 1
+echo "== PMC passes (launch configuration of the timed region: split-K factors for the side stream; the profiler serialises the kernels)"
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pF" -- python3 "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/pF.log" 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pW" -- python3 "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/pW.log" 2>&1 || exit 1
 echo "== kernel trace (timeline of 4 steady-state steps)"
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/pT" -- python3 "$R/bench.py" --steps 4 --warmup 3 --no-cpu-baseline --no-kernel-timing > "$OUT/pT.log" 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/pT" -- python3 "$R/bench.py" --steps 4 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/pT.log" 2>&1 || exit 1
 cp $(ls "$OUT"/p1/*/*_kernel_stats.csv | head -n 1) "$OUT/bench_kernel_stats.csv"
 cp $(ls "$OUT"/p3/*/*_kernel_stats.csv | head -n 1) "$OUT/bench_kernel_stats_timed_region.csv"
 cp $(ls "$OUT"/p2/*/*_kernel_stats.csv | head -n 1) "$OUT/bench_kernel_stats_single_stream.csv"
 cp $(ls "$OUT"/pF/*/*_counter_collection.csv | head -n 1) "$OUT/pmc_fetch.csv"
 cp $(ls "$OUT"/pW/*/*_counter_collection.csv | head -n 1) "$OUT/pmc_write.csv"
 cp $(ls "$OUT"/pT/*/*_kernel_trace.csv | head -n 1) "$OUT/kernel_trace.csv"
-python3 "$R/tools/pmc_traffic.py" "$OUT/pmc_fetch.csv" "$OUT/pmc_write.csv" "$OUT/pmc_traffic.json"
+python3 "$R/tools/pmc_traffic.py" "$OUT/pmc_fetch.csv" "$OUT/pmc_write.csv" "$OUT/pmc_traffic.json" "timed region (weight gradients split for half the work-group slots, as beside the dgrad chain)" | tee "$OUT/pmc_traffic.txt"
 python3 "$R/tools/timeline.py" "$OUT/kernel_trace.csv" | tee "$OUT/timeline.txt"
 rm -rf "$OUT/p1" "$OUT/p2" "$OUT/p3" "$OUT/pF" "$OUT/pW" "$OUT/pT" "$OUT/pmc_fetch.csv" "$OUT/pmc_write.csv"      # keep the summaries only
 echo "== hipGraph replay vs eager launches"
