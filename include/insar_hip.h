@@ -309,6 +309,11 @@ int insar_bnse_bwd_coef(const InsarBnSeBwd* d, const float* red, int32_t rows, c
 int insar_bnse_bwd_coef_fused(const InsarBnSeBwd* d, const float* red, int32_t rows, const float* scale,
                               const float* shift, float* ws, float* dconv_bias, int32_t training, uint32_t* ticket,
                               void* stream);
+/* Units WITHOUT an SE gate (d->use_se == 0): the coefficients (k1, k2, dgamma, dbeta, conv-bias gradient) from ALL
+ * `rows_total` rows of the reduction slab red[rows_total][2][C] in one channel-parallel launch; any partition of the pixels
+ * into rows will do (BatchNorm backward, :82-83,85-86 inside loss.backward(), :345). */
+int insar_bn_bwd_coef(const InsarBnSeBwd* d, const float* red, int64_t rows_total, const float* scale,
+                      float* dconv_bias, int32_t training, void* stream);
 int insar_bnrelu_bwd_apply(const InsarAct* dout, const InsarAct* y, const float* scale,
                            const float* shift, const float* mean, const float* invstd,
                            const float* gate, const float* coefB, const float* k1,

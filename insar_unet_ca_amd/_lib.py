@@ -128,6 +128,7 @@ _SIGNATURES = {
     "insar_bnrelu_bwd_reduce": [_AP, _AP, _P, _P, _P, _I, _I, _P],
     "insar_bnse_bwd_coef": [C.POINTER(InsarBnSeBwd), _P, _I, _P, _P, _P, _P, _I, _P],
     "insar_bnse_bwd_coef_fused": [C.POINTER(InsarBnSeBwd), _P, _I, _P, _P, _P, _P, _I, _P, _P],
+    "insar_bn_bwd_coef": [C.POINTER(InsarBnSeBwd), _P, _L, _P, _P, _I, _P],
     "insar_bnrelu_bwd_apply": [_AP, _AP, _P, _P, _P, _P, _P, _P, _P, _P, _AP, _I, _P],
     "insar_bn_relu_apply_pool_arg": [_AP, _P, _P, _P, _AP, _AP, _P, _I, _P],
     "insar_bnrelu_bwd_reduce_pool": [_AP, _AP, _P, _AP, _P, _P, _P, _I, _I, _P],

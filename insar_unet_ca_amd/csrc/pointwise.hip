@@ -1286,6 +1286,14 @@ __global__ void bnse_bwd_stage2(BnSeBwdArgs a) {
   bnse_stage2_elem<false>(a, blockIdx.x * (int64_t)blockDim.x + threadIdx.x);
 }
 
+// (Since round 3 the DEFAULT for units without an SE gate is insar_bn_bwd_coef below: one channel-parallel launch, no
+// hand-off between work-groups at all. This kernel stays as the INSAR_COEF_SIMPLE=0 variant. Its hand-off relies on
+// gfx950 behaviour rather than on the HSA memory model: the stage-1 results are relaxed agent-scope atomic stores, which
+// the compiler emits as `global_store ... sc1` — written through to memory, past the XCD's L2 —, every wave drains them
+// with s_waitcnt vmcnt(0) before the work-group's barrier, and only then does lane 0 draw the ticket (a relaxed agent-scope
+// RMW, executed at the memory side); the last arriver reads with relaxed agent-scope atomic loads (`sc1`: served past its
+// own L1 / L2). MI355X_MICROARCH.md, "Valid forms", measures exactly this store / drain / counter / sc1-load sequence;
+// what it does not give is a formal release / acquire edge, which is why it is no longer the default.)
 // Both stages in ONE launch, for units WITHOUT an SE gate (stage 2 is then C elements of 2 * B loads): every work-group runs
 // stage 1 for its image with the hand-off results written through to memory, drains its stores and draws a ticket; the
 // work-group that draws the last one runs stage 2, reading the hand-off data past the caches. One launch less on the
@@ -1322,6 +1330,11 @@ static int launch_bnse_coef(const char* who, const InsarBnSeBwd* d, const float*
   hipStream_t s = (hipStream_t)stream;
   if (stages & 1) {
     size_t lds = (size_t)(3 * d->C + d->Cr + 1 + COEF_THREADS) * sizeof(float);
+    if (lds > 64 * 1024) {
+      static std::atomic<uint64_t> attr_mask{0};
+      hipError_t e = insar_set_lds_once(attr_mask, (const void*)bnse_bwd_stage1, 160 * 1024);
+      if (e != hipSuccess) INSAR_FAIL(-(int)e, "%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
+    }
     hipLaunchKernelGGL(bnse_bwd_stage1, dim3(d->B), dim3(COEF_THREADS), lds, s, a);
   }
   if (stages & 2) {
@@ -1351,8 +1364,67 @@ extern "C" int insar_bnse_bwd_coef_fused(const InsarBnSeBwd* d, const float* red
   if (d->C > 8192 || d->B < 1 || rows < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_bnse_bwd_coef_fused: bad shape");
   BnSeBwdArgs a; a.d = *d; a.red = red; a.rows = rows; a.scale = scale; a.shift = shift; a.ws = ws; a.dconv_bias = dconv_bias; a.training = training;
   size_t lds = (size_t)(3 * d->C + d->Cr + 1 + COEF_THREADS) * sizeof(float);
+  if (lds > 64 * 1024) {           // C above ~5000: more dynamic LDS than a kernel gets without the attribute (per device)
+    static std::atomic<uint64_t> attr_mask{0};
+    hipError_t e = insar_set_lds_once(attr_mask, (const void*)bnse_bwd_fused, 160 * 1024);
+    if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_bnse_bwd_coef_fused: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
   hipLaunchKernelGGL(bnse_bwd_fused, dim3(d->B), dim3(COEF_THREADS), lds, (hipStream_t)stream, a, (unsigned int*)ticket);
   INSAR_CHECK_LAUNCH("insar_bnse_bwd_coef_fused");
+  return INSAR_OK;
+}
+
+// Units WITHOUT an SE gate: the coefficients are linear in the slab rows, so the per-image stage is not needed — ONE launch
+// whose work-groups own 64 channels each and fold ALL rows (B * rows of them, any partition of the pixels):
+//   P = sum_rows red[.][0][c], Q = sum_rows red[.][1][c];  dbeta = P;  dgamma = invstd * (Q - mean * P);
+//   k1 = dbeta / N, k2 = dgamma / N (training; 0 in eval mode);  conv-bias gradient 0 (training) / scale * dbeta (eval).
+// 256 threads = 64 channels x 4 row groups (coalesced 256-byte row segments), folded through LDS in a fixed order:
+// deterministic, no hand-off between work-groups (the two-stage kernels above run 16 work-groups and then one).
+__global__ void __launch_bounds__(256) bn_bwd_coef_kernel(const float* __restrict__ red, int64_t rows, int C,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ scale, float inv_count, int training,
+                                                          int accumulate, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ dconv_bias) {
+  __shared__ float sp[4][64], sq[4][64];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float p = 0.f, q = 0.f;
+  if (c < C) {
+    int64_t r = g;
+    for (; r + 12 < rows; r += 16) {            // four rows of this group in flight
+      const float* b = red + r * 2 * C + c;
+      const float p0 = b[0], q0 = b[C], p1 = b[8 * (int64_t)C], q1 = b[9 * (int64_t)C];
+      const float p2 = b[16 * (int64_t)C], q2 = b[17 * (int64_t)C], p3 = b[24 * (int64_t)C], q3 = b[25 * (int64_t)C];
+      p += p0; q += q0; p += p1; q += q1; p += p2; q += q2; p += p3; q += q3;
+    }
+    for (; r < rows; r += 4) { p += red[r * 2 * C + c]; q += red[(r * 2 + 1) * C + c]; }
+  }
+  sp[g][cl] = p; sq[g][cl] = q;
+  __syncthreads();
+  if (g == 0 && c < C) {
+    const float P = (sp[0][cl] + sp[1][cl]) + (sp[2][cl] + sp[3][cl]);
+    const float Q = (sq[0][cl] + sq[1][cl]) + (sq[2][cl] + sq[3][cl]);
+    const float dg = invstd[c] * (Q - mean[c] * P);
+    k1[c] = training ? P * inv_count : 0.f;
+    k2[c] = training ? dg * inv_count : 0.f;
+    if (accumulate) { dgamma[c] += dg; dbeta[c] += P; } else { dgamma[c] = dg; dbeta[c] = P; }
+    if (dconv_bias) {
+      const float v = training ? 0.f : scale[c] * P;
+      if (accumulate) dconv_bias[c] += v; else dconv_bias[c] = v;
+    }
+  }
+}
+
+extern "C" int insar_bn_bwd_coef(const InsarBnSeBwd* d, const float* red, int64_t rows_total, const float* scale,
+                                 float* dconv_bias, int32_t training, void* stream) {
+  if (!d || !red || !scale || !d->mean || !d->invstd || !d->dgamma || !d->dbeta || !d->k1 || !d->k2)
+    INSAR_FAIL(INSAR_E_ARG, "insar_bn_bwd_coef: null pointer");
+  if (d->use_se) INSAR_FAIL(INSAR_E_ARG, "insar_bn_bwd_coef: units with an SE gate need insar_bnse_bwd_coef (per-image stage)");
+  if (d->C < 1 || d->B < 1 || rows_total < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_bn_bwd_coef: bad shape");
+  const float inv_count = 1.f / ((float)d->B * (float)d->H * (float)d->W);
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((d->C + 63) / 64), dim3(256), 0, (hipStream_t)stream, red, rows_total, d->C, d->mean,
+                     d->invstd, scale, inv_count, training, d->accumulate, d->dgamma, d->dbeta, d->k1, d->k2, dconv_bias);
+  INSAR_CHECK_LAUNCH("insar_bn_bwd_coef");
   return INSAR_OK;
 }
 

@@ -113,7 +113,15 @@ class _DeepLabV3(nn.Module):
 
 class DeepLabV3_SingleChannel_Attn(nn.Module):
     """Same constructor, attribute names and state_dict as the reference's wrapper (:83-137); forward (:140-162) on HIP.
-    `pretrained=True` would need torchvision's ImageNet download (a network fetch): refused."""
+
+    Initialisation differs from the reference's call site in ONE respect, and it matters for anyone comparing training
+    curves: `deeplabv3_resnet50(pretrained=False)` (:92) still loads ImageNet weights into the BACKBONE (torchvision's
+    legacy `pretrained_backbone=True` default -> `weights_backbone=IMAGENET1K_V1`, a network fetch), while this class —
+    torchvision and the network being absent — starts the backbone from torch's default (kaiming) initialisation.
+    To start where the reference starts, load a ResNet-50 ImageNet state_dict with `load_backbone_state_dict` (conv1 is
+    mean-reduced over its three input channels exactly as :105-118 does). `pretrained=True` (the COCO-trained head, another
+    fetch) is refused; a reference checkpoint made that way loads through `load_state_dict`, which drops the
+    `model.aux_classifier.*` entries such a model carries (this class has no aux head: the forward pass never uses it)."""
 
     def __init__(self, num_classes: int = 2, backbone: str = "resnet50", pretrained: bool = False,
                  compute_dtype: Optional[torch.dtype] = None):
@@ -134,6 +142,26 @@ class DeepLabV3_SingleChannel_Attn(nn.Module):
         self.compute_dtype = compute_dtype
         self._plans = _PlanCache()
         self._hooks: dict = {}
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        """As nn.Module.load_state_dict, except that `model.aux_classifier.*` keys (present in checkpoints of a reference model
+        built with pretrained=True: torchvision then adds an FCNHead that `forward` never calls, :140-162) are ignored."""
+        aux = [k for k in state_dict if k.startswith("model.aux_classifier.")]
+        if aux:
+            state_dict = OrderedDict((k, v) for k, v in state_dict.items() if not k.startswith("model.aux_classifier."))
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    @torch.no_grad()
+    def load_backbone_state_dict(self, resnet_state_dict, strict: bool = True):
+        """Load a torchvision ResNet-50 state_dict (e.g. IMAGENET1K weights from a local file) into the backbone, as the
+        reference's constructor effectively does (:92, `weights_backbone`): `fc.*` is dropped, and the 3-channel `conv1.weight`
+        (64, 3, 7, 7) becomes the 1-channel stem by averaging over the input channels — the reference's own rule for
+        pretrained stems (:105-118)."""
+        sd = OrderedDict((k, v) for k, v in resnet_state_dict.items() if not k.startswith("fc."))
+        w = sd.get("conv1.weight")
+        if w is not None and w.shape[1] == 3:
+            sd["conv1.weight"] = w.mean(dim=1, keepdim=True)
+        return self.backbone.load_state_dict(sd, strict=strict)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         _require_device(x, "DeepLabV3_SingleChannel_Attn")
@@ -210,6 +238,19 @@ class ConvUnit:
         self.w = GemmWeight(ctx, conv.weight, "conv3")
         self._class_w = {}
         self._tmp_grad = None
+        self._ticket = None                       # last-arriver counter of the single-launch coefficient stages
+        # BatchNorm-backward sums written by the epilogue of the GEMM that produces this unit's incoming gradient
+        # (engine.ConvBN.bstat_slab, InsarBstat)
+        self.bred, self.bred_rows, self.bred_ready = None, 0, False
+
+    def bstat_slab(self, rows_total: int, per_image: bool):
+        B = self.x.B
+        if not self.relu or (per_image and rows_total % B):
+            return None
+        rows = -(-rows_total // B)
+        if self.bred is None or self.bred_rows != rows:
+            self.bred, self.bred_rows = self.ctx.f32(B * rows, 2, self.cout), rows
+        return self.bred, (self.y, self.scale, self.shift)
 
     def params(self):
         return [self.conv.weight, self.bn.weight, self.bn.bias]
@@ -246,36 +287,56 @@ class ConvUnit:
 
     # ---- backward -----------------------------------------------------------------------------------------
     def backward(self, dout: Act, sink: GradSink, training: bool, dx: Optional[Act], relu: Optional[bool] = None,
-                 add: Optional[Act] = None) -> None:
+                 add: Optional[Act] = None, bstat_for: Optional["ConvUnit"] = None) -> None:
         """dout: gradient wrt the unit's output. `relu` overrides the unit's own flag (the residual unit's caller has
-        already gated dout with the block's ReLU). dx (nullable): receives the input gradient, plus `add` if given."""
+        already gated dout with the block's ReLU). dx (nullable): receives the input gradient, plus `add` if given.
+        bstat_for: the unit whose incoming gradient dx is (and nothing else is added to it afterwards): its BatchNorm-backward
+        sums come out of the epilogue of this unit's input-gradient GEMM."""
         ctx, s = self.ctx, _lib.stream_ptr()
         relu = self.relu if relu is None else relu
         B = self.x.B
         if self.dy is None:
             self.dy = Act.alloc(B, self.Ho, self.Wo, self.cout, ctx.dtype, ctx.device)
-        call("insar_bnrelu_bwd_reduce", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.red_part), int(relu),
-             self.red_rpp, s)
+        fused = self.bred_ready and relu
+        self.bred_ready = False
+        if not fused:
+            call("insar_bnrelu_bwd_reduce", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.red_part), int(relu),
+                 self.red_rpp, s)
+        red, red_rows = (self.bred, self.bred_rows) if fused else (self.red_part, self.red_rows)
         d = InsarBnSeBwd()
         d.B, d.H, d.W, d.C, d.Cr, d.use_se = B, self.Ho, self.Wo, self.cout, 1, 0
         d.mean, d.invstd = ptr(self.mean), ptr(self.invstd)
         d.dgamma, d.dbeta = ptr(sink.view(self.bn.weight)), ptr(sink.view(self.bn.bias))
         d.k1, d.k2 = ptr(self.k1), ptr(self.k2)
         d.accumulate = 0
-        call("insar_bnse_bwd_coef", C.byref(d), ptr(self.red_part), self.red_rows, ptr(self.scale), ptr(self.shift),
-             ptr(self.bwd_ws), 0, int(training), s)
+        if engine.COEF_SIMPLE:      # no SE gate: one channel-parallel launch over all slab rows
+            call("insar_bn_bwd_coef", C.byref(d), ptr(red), red_rows * B, ptr(self.scale), 0, int(training), s)
+        elif engine.COEF_FUSE:      # both coefficient stages in one launch (stage 2 by the last-arriving work-group)
+            if self._ticket is None:
+                self._ticket = torch.zeros(1, dtype=torch.int32, device=ctx.device)
+            call("insar_bnse_bwd_coef_fused", C.byref(d), ptr(red), red_rows, ptr(self.scale), ptr(self.shift),
+                 ptr(self.bwd_ws), 0, int(training), ptr(self._ticket), s)
+        else:
+            call("insar_bnse_bwd_coef", C.byref(d), ptr(red), red_rows, ptr(self.scale), ptr(self.shift),
+                 ptr(self.bwd_ws), 0, int(training), s)
         call("insar_bnrelu_bwd_apply", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.mean), ptr(self.invstd),
              0, 0, ptr(self.k1), ptr(self.k2), self.dy.ref, int(relu), s)
         with ctx.side_stream():
             self._weight_grad(sink.view(self.conv.weight))
         if dx is not None:
-            self._input_grad(dx, add)
+            self._input_grad(dx, add, bstat_for)
 
-    def _input_grad(self, dx: Act, add: Optional[Act]) -> None:
+    def _input_grad(self, dx: Act, add: Optional[Act], bstat_for: Optional["ConvUnit"] = None) -> None:
         H, W = self.x.H, self.x.W
         if self.s == 1:
             taps = [(-dy, -dx_) for dy, dx_ in self.taps]
-            _igemm(self.dy, dx, self._wptr("dgrad"), self.cin, H, W, 1, taps, 0, oob=self.oob, add=add)
+            slab = None
+            if add is None and bstat_for is not None:
+                slab = engine._igemm_bstat_slab(bstat_for, False, self.x.B * H * W, self.cin, H * W, dx)
+            _igemm(self.dy, dx, self._wptr("dgrad"), self.cin, H, W, 1, taps, 0, oob=self.oob, add=add,
+                   stats=slab[0] if slab else None, bstat=slab[1] if slab else None)
+            if slab:
+                bstat_for.bred_ready = True
             return
         # stride 2: the input gradient of a strided convolution, one launch per parity class of the input pixel
         wd = self.w.dgrad()                                     # [T][Ci][Co]
@@ -373,8 +434,8 @@ class BottleneckPlan:
             self.dz2 = Act.alloc(b.B, b.H, b.W, b.c_len, ctx.dtype, ctx.device)
         # out = relu(bn3(conv3) + identity): gate the incoming gradient once, in place; both branches take it
         call("insar_relu_gate_bwd", g.ref, self.out.ref, g.ref, _lib.stream_ptr())
-        self.u3.backward(g, sink, training, self.dz2, relu=False)
-        self.u2.backward(self.dz2, sink, training, self.dz1)
+        self.u3.backward(g, sink, training, self.dz2, relu=False, bstat_for=self.u2)
+        self.u2.backward(self.dz2, sink, training, self.dz1, bstat_for=self.u1)
         if self.ud is None:
             self.u1.backward(self.dz1, sink, training, dx, add=g)            # identity branch: dx = dgrad + g
         else:

@@ -270,6 +270,7 @@ PREP_SIDE = os.environ.get("INSAR_PREP_SIDE", "1") != "0"         # diagnostic: 
 OUTC_FUSE = os.environ.get("INSAR_OUTC_FUSE", "1") != "0"        # diagnostic: 0 materialises the gradient of outc's input
 WGRAD_GRID_CAP = int(os.environ.get("INSAR_WGRAD_GRID_CAP", "200"))    # 8-wave weight-gradient launches beside the dgrad chain: at most this many work-groups (0 = off)
 COEF_FUSE = os.environ.get("INSAR_COEF_FUSE", "1") != "0"        # diagnostic: 0 = two launches for the coefficient stages of every unit
+COEF_SIMPLE = os.environ.get("INSAR_COEF_SIMPLE", "1") != "0"    # units without an SE gate: the channel-parallel one-launch kernel (0 = the ticket kernel)
 OUTC_WGRAD_FUSE = os.environ.get("INSAR_OUTC_WGRAD_FUSE", "1") != "0"   # diagnostic: 0 = outc's weight gradient in its own pass over y
 WGRAD_FILL_T = float(os.environ.get("INSAR_WGRAD_FILL_T", "0.5"))   # the same for the transposed convs' per-tap weight gradient
 WGRAD_FILL_ALONE = float(os.environ.get("INSAR_WGRAD_FILL_ALONE", "1.0"))   # ... and when it has the GPU to itself
@@ -620,9 +621,12 @@ class ConvBN:
              _lib.stream_ptr())
 
     def _coef(self, coef_args, s, se) -> None:
-        """Both coefficient stages: ONE launch for a unit without an SE gate (stage 2 by the work-group that finishes stage 1
-        last; COEF_FUSE), else two (with a gate stage 2 carries the SE weight gradients, too much for one work-group)."""
-        if COEF_FUSE and se is None:
+        """The backward coefficients. A unit without an SE gate: one channel-parallel launch over all slab rows
+        (insar_bn_bwd_coef; COEF_SIMPLE=0: the per-image stage + batch fold in one launch, stage 2 by the work-group that
+        finishes stage 1 last). With a gate: two launches (stage 2 carries the SE weight gradients)."""
+        if COEF_SIMPLE and se is None:       # no SE gate: the coefficients are linear in the slab rows — one channel-parallel launch
+            call("insar_bn_bwd_coef", coef_args[0], coef_args[1], coef_args[2] * self.x.B, coef_args[3], coef_args[6], coef_args[7], s)
+        elif COEF_FUSE and se is None:
             if self._ticket is None:
                 self._ticket = torch.zeros(1, dtype=torch.int32, device=self.ctx.device)
             call("insar_bnse_bwd_coef_fused", *coef_args, ptr(self._ticket), s)

@@ -245,3 +245,97 @@ def test_deeplab_bf16_config5_geometry(dev):
         l.backward()
         opt.step()
     assert float(l) < first
+
+
+def _oracle_autocast_bf16(sd, x, y):
+    """The oracle's training-mode forward + backward under torch's CPU autocast(bfloat16): what torch itself makes of this
+    network in bf16 (convolutions in bf16, BatchNorm statistics in fp32), on the same weights and input."""
+    names = [k for k in dlo.primary_keys(sd) if dlo.is_param(k)]
+    work = OrderedDict((k, sd[k].clone()) for k in dlo.primary_keys(sd))
+    leaves = []
+    for k in names:
+        work[k] = work[k].clone().requires_grad_(True)
+        leaves.append(work[k])
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        out = dlo.forward(work, x, training=True)
+    loss = dlo.cross_entropy(out.float(), y)
+    grads = dict(zip(names, torch.autograd.grad(loss, leaves)))
+    return out.detach().float(), float(loss), grads
+
+
+@pytest.mark.parametrize("shape", [(4, 1, 64, 64), (2, 1, 128, 128)])
+def test_deeplab_bf16_training_mode_against_torchs_own_bf16(dev, shape):
+    """The numerical contract of config 5 in the arithmetic it is benchmarked in (bf16, TRAINING mode,
+    DeepLabV3-ChannelAttention.py:140-162): reference = the oracle in float64; yardstick = torch's own bf16 (CPU autocast)
+    on the same weights and input. 53 layers of batch statistics over small maps amplify any rounding, bf16's included, so
+    both are far from the float64 result; the HIP bf16 path (bf16 storage, fp32 accumulation and statistics) must not be
+    further from it than twice torch's own bf16: at the logits (rel-L2), in the loss, and per parameter-gradient tensor
+    (rel-L2 within 2x torch's on that tensor, or within 2x torch's median: different roundings flip different ReLU / max-pool
+    decisions), with the median over tensors within 2x torch's median."""
+    import insar_unet_ca_amd as iu
+    net, sd = _make(dev, 51, dtype=torch.bfloat16, p_drop=0.0)
+    net.train()
+    x, y = _input(shape, 23)
+    ref, ref_loss, g64, _ = _oracle_grads(sd, x, y, torch.float64)
+    t_out, t_loss, tg = _oracle_autocast_bf16(sd, x, y)
+    logits = net(x.to(dev))
+    loss = iu.CrossEntropyLoss(ignore_index=255)(logits, y.to(dev))
+    loss.backward()
+    e_hip, e_torch = rel_l2(logits, ref), rel_l2(t_out, ref)
+    print(f"config-5 bf16 training mode {shape}: logits rel-L2 vs float64: HIP {e_hip:.3e}, torch autocast bf16 {e_torch:.3e}; "
+          f"loss HIP {float(loss.detach()):.5f} torch-bf16 {t_loss:.5f} float64 {ref_loss:.5f}")
+    assert e_hip <= 2 * e_torch + 1e-3
+    assert abs(float(loss.detach()) - ref_loss) <= 2 * abs(t_loss - ref_loss) + 5e-3 * abs(ref_loss)
+    got = {k: p.grad for k, p in net.named_parameters()}
+    names = [k for k in g64 if float(g64[k].abs().max()) >= 1e-12]
+    hip = {k: rel_l2(got[k], g64[k]) for k in names}
+    tor = {k: rel_l2(tg[k], g64[k]) for k in names}
+    med_h, med_t = float(np.median(list(hip.values()))), float(np.median(list(tor.values())))
+    bad = {k: (hip[k], tor[k]) for k in names if hip[k] > max(2 * tor[k], 2 * med_t)}
+    print(f"   gradient rel-L2 vs float64, median over {len(names)} tensors: HIP {med_h:.3e}, torch autocast bf16 {med_t:.3e}; "
+          f"worst HIP {max(hip.values()):.3e}, worst torch {max(tor.values()):.3e}")
+    assert med_h <= 2 * med_t
+    assert len(bad) <= max(2, len(names) // 50), sorted(bad.items(), key=lambda kv: -kv[1][0])[:6]
+
+
+@pytest.mark.parametrize("dtype,tol_curve,tol_final", [(torch.float32, 0.07, 0.02), (torch.bfloat16, 0.07, 0.05)])
+def test_deeplab_convergence_tracks_the_oracle(dev, dtype, tol_curve, tol_final):
+    """Thirty Adam(lr=1e-4) steps of DeepLabV3-CA on four 64 x 64 tiles, dropout off: the HIP loss curve (fp32 and bf16)
+    against the oracle's own fp32 training run on the same weights and batches (torch CPU). After a few steps the two
+    trajectories are different roundings of a chaotic system, so the gates are on the curve, not on its elements: every
+    loss within tol_curve of the oracle's at the same step relative to the first loss, the mean of the last five within
+    tol_final, and the loss must come down by at least as large a share as the oracle's does, less a fifth. Measured on
+    MI355X: fp32 0.6568 -> 0.2678 (oracle 0.2708), largest difference along the curve 3.4 % of the first loss; bf16
+    0.6509 -> 0.2842, 3.1 %: gates at twice the measured figures."""
+    import insar_unet_ca_amd as iu
+    net, sd = _make(dev, 61, dtype=dtype, p_drop=0.0)
+    net.train()
+    batches = [_input((4, 1, 64, 64), 30 + 4 * i) for i in range(3)]
+    crit = iu.CrossEntropyLoss(ignore_index=255)
+    opt = iu.Adam(net.parameters(), lr=1e-4)
+    names = [k for k in dlo.primary_keys(sd) if dlo.is_param(k)]
+    ref_params = [sd[k].clone().requires_grad_(True) for k in names]
+    ropt = torch.optim.Adam(ref_params, lr=1e-4)
+    work = OrderedDict((k, sd[k].clone()) for k in dlo.primary_keys(sd))
+    for k, p in zip(names, ref_params):
+        work[k] = p
+    hip, ref = [], []
+    steps = 30
+    for i in range(steps):
+        x, y = batches[i % 3]
+        opt.zero_grad()
+        l = crit(net(x.to(dev)), y.to(dev))
+        l.backward()
+        opt.step()
+        hip.append(float(l.detach()))
+        ropt.zero_grad()
+        rl = dlo.cross_entropy(dlo.forward(work, x, training=True), y)        # updates the BatchNorm buffers in `work`
+        rl.backward()
+        ropt.step()
+        ref.append(float(rl))
+    print(f"DeepLabV3-CA {dtype} convergence: HIP {hip[0]:.4f} -> {np.mean(hip[-5:]):.4f}, oracle {ref[0]:.4f} -> {np.mean(ref[-5:]):.4f}; "
+          f"largest |difference| {max(abs(a - b) for a, b in zip(hip, ref)):.4f}")
+    assert all(abs(a - b) <= tol_curve * ref[0] for a, b in zip(hip, ref)), list(zip(hip, ref))
+    assert abs(np.mean(hip[-5:]) - np.mean(ref[-5:])) <= tol_final * ref[0]
+    drop_ref, drop_hip = 1 - np.mean(ref[-5:]) / ref[0], 1 - np.mean(hip[-5:]) / hip[0]
+    assert drop_ref > 0.02 and drop_hip >= 0.8 * drop_ref

@@ -291,3 +291,26 @@ def test_deeplab_state_dict_contract_and_tap_logic():
     live = deeplab._live
     assert live(8, 8, 1, 0) and live(8, 8, 1, -7) and not live(8, 8, 1, -8) and not live(8, 8, 1, 12)
     assert live(32, 32, 1, 24) and not live(32, 32, 1, 36) and live(32, 64, 2, -1) and live(32, 64, 2, 1)
+
+
+def test_deeplab_checkpoint_loaders_follow_the_reference_call_site():
+    """(1) a reference checkpoint made with pretrained=True carries model.aux_classifier.* keys the forward pass
+    never uses: a strict load ignores them; (2) the reference's pretrained=False call site still starts from an ImageNet
+    ResNet-50 backbone: load_backbone_state_dict takes such a state_dict, dropping fc.* and mean-reducing the 3-channel stem
+    (DeepLabV3-ChannelAttention.py:105-118)."""
+    from collections import OrderedDict
+    import torch
+    import insar_unet_ca_amd as iu
+    net = iu.DeepLabV3_SingleChannel_Attn(2)
+    sd = OrderedDict(net.state_dict())
+    sd["model.aux_classifier.0.weight"] = torch.zeros(256, 1024, 3, 3)
+    sd["model.aux_classifier.4.bias"] = torch.zeros(21)
+    res = net.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    resnet = OrderedDict((k[len("backbone."):], torch.randn_like(v) if v.is_floating_point() else v.clone())
+                         for k, v in net.state_dict().items() if k.startswith("backbone."))
+    resnet["conv1.weight"] = torch.randn(64, 3, 7, 7)
+    resnet["fc.weight"], resnet["fc.bias"] = torch.zeros(1000, 2048), torch.zeros(1000)
+    net.load_backbone_state_dict(resnet)
+    assert torch.allclose(net.backbone["conv1"].weight, resnet["conv1.weight"].mean(1, keepdim=True))
+    assert torch.equal(net.model.backbone["layer3"][2].conv2.weight, resnet["layer3.2.conv2.weight"])

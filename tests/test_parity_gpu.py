@@ -11,7 +11,8 @@ Tolerances
                   the kernel's own operands); block/network gradient tests use rel-L2 with a floor
                   derived from torch's own fp32-vs-fp64 disagreement on the same fixture.
   bf16          : calibrated against torch's own bf16 on the same fixture (max-rel 0.08-0.10,
-                  98.3-98.7 % argmax agreement, measured in-container): gates 0.15 / 97.5 %.
+                  98.3-98.7 % argmax agreement, measured in-container); the HIP path measures 8.2e-2 / 98.5 % on G3 and
+                  5.8e-2 / 98.6 % on G3r: gates 0.12 / 98 % (G3) and 8.5e-2 / 98 % (G3r).
 """
 import ctypes as C
 from collections import OrderedDict
@@ -29,8 +30,8 @@ pytestmark = pytest.mark.gpu
 
 FWD_TOL = 1e-3          # north_star
 KERNEL_TOL = 2e-5
-BF16_FWD_TOL = 0.15
-BF16_ARGMAX = 0.975
+BF16_FWD_TOL = 0.12          # G3 fixtures: measured 8.2e-2 (torch's own bf16 on them: 0.08-0.10); 1.5x measured
+BF16_ARGMAX = 0.98           # measured 0.9854 (torch's own: 0.983-0.987)
 
 
 @pytest.fixture(scope="module")
@@ -752,11 +753,15 @@ def test_unet_fp32_gradients_given_equal_relu_decisions(dev, fixture, shape):
             assert e <= (0.35 if k.endswith("fc.0.weight") else 0.1), f"bf16: gradient rel-L2 {e:.3e} at {k}"
         return
     smooth = fixture == "closed-form"      # degenerate (near-constant) channels: invstd up to 316 amplifies the noise
-    assert flips <= (2000 if smooth else 40) and worst_z < (1e-2 if smooth else 1e-4) and pool_flips <= (2000 if smooth else 40), \
+    # closed-form 256x256: measured 425 ReLU decisions (largest |z| 1.1e-3) and 10 pool decisions differ: gates at 2x
+    assert flips <= (850 if smooth else 40) and worst_z < (2.2e-3 if smooth else 1e-4) and pool_flips <= 40, \
         f"{flips} ReLU decisions differ, largest |z| there {worst_z:.2e}; {pool_flips} pool decisions differ"
-    # generic position: measured 1e-5 ... 2.5e-5. Closed-form 256x256 (B=1, near-constant channels whose
-    # invstd of up to 316 amplifies rounding noise; torch's own fp32 is off by 0.1 here): measured 5e-4, SE fc 6e-3.
-    assert worst <= (2e-2 if smooth else 2e-4), f"worst gradient rel-L2 {worst:.3e} at {name} ({flips} flips)"
+    # generic position: measured 1e-5 ... 2.5e-5, gate 2e-4. Closed-form 256x256 (B=1, near-constant channels whose
+    # invstd of up to 316 amplifies rounding noise; torch's own fp32 is off by 0.1 here): measured 5.9e-4 for every conv /
+    # BN / convT tensor and 8.0e-3 for the bottleneck's first SE Linear: gates at 2x measured.
+    for e, k in errs:
+        gate = (1.6e-2 if k.endswith("fc.0.weight") else 1.2e-3) if smooth else 2e-4
+        assert e <= gate, f"gradient rel-L2 {e:.3e} at {k} (gate {gate:.1e}; {flips} flips)"
 
 
 @pytest.mark.parametrize("use_se,cin", [(False, 2), (True, 1)])
@@ -839,8 +844,10 @@ def test_unet_bf16_against_golden(dev, golden, tag, shape):
     loss.backward()
     ref = torch.from_numpy(g3[f"{tag}/logits/full"]) if f"{tag}/logits/full" in g3.files else None
     if ref is not None:
-        assert max_rel(logits, ref) <= BF16_FWD_TOL
+        err = max_rel(logits, ref)
         agree = (logits.argmax(1).cpu() == ref.argmax(1)).float().mean().item()
+        print(f"bf16 vs reference on G3 {tag}: max-rel {err:.3e}, arg-max agreement {agree:.4f}")
+        assert err <= BF16_FWD_TOL
         assert agree >= BF16_ARGMAX
     else:
         check_summary(g3, f"{tag}/logits", logits, BF16_FWD_TOL)
@@ -1054,6 +1061,7 @@ def test_split_backward_coefficients_are_bitwise_the_fused_launch(dev, dtype, mo
     same gradient bits as insar_bnse_bwd_coef followed by insar_bnrelu_bwd_apply on the dgrad chain."""
     import insar_unet_ca_amd as iu
     from insar_unet_ca_amd import engine
+    monkeypatch.setattr(engine, "COEF_SIMPLE", False)      # the split schedule is a variant of the two-stage kernels
     from insar_unet_ca_amd.data import make_batch
     x, y = make_batch(3, 3, 48)
     x, y = x.to(dev), y.to(dev)
@@ -1141,6 +1149,7 @@ def test_single_launch_coefficient_stages_are_bitwise_the_two_launches(dev, dtyp
     x, y = make_batch(4, 16, 64)
     x, y = x.to(dev), y.to(dev)
     ref = None
+    monkeypatch.setattr(engine, "COEF_SIMPLE", False)          # this test is about the ticket kernel
     for fuse, reps in ((False, 1), (True, 30)):
         monkeypatch.setattr(engine, "COEF_FUSE", fuse)
         torch.manual_seed(5)
@@ -1159,6 +1168,39 @@ def test_single_launch_coefficient_stages_are_bitwise_the_two_launches(dev, dtyp
             else:
                 bad = [n for n, a, b in zip(names, g, ref) if not torch.equal(a, b)]
                 assert not bad, (rep, bad[:6])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_channel_parallel_coefficient_kernel_against_the_two_stage_kernels(dev, dtype, monkeypatch):
+    """insar_bn_bwd_coef (units without an SE gate: k1, k2, dgamma, dbeta from all slab rows in one channel-parallel
+    launch) against the per-image stage + batch fold: the same sums in another order. fp32: every gradient within 2e-5
+    rel-L2; bf16: k1 / k2 differ in the last bits, which moves a few roundings of dy: within a quarter of the distance
+    between the bf16 and the fp32 gradient of that tensor + 1e-3 of its norm (the yardstick of tests/test_bstat_gpu.py)."""
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd import engine
+    from insar_unet_ca_amd.data import make_batch
+    x, y = (t.to(dev) for t in make_batch(4, 8, 64))
+
+    def run(simple, dt):
+        monkeypatch.setattr(engine, "COEF_SIMPLE", simple)
+        torch.manual_seed(5)
+        net = iu.UNet(2, 2, True, compute_dtype=dt).to(dev).train()
+        loss = iu.DiceCELoss(ignore_index=255)(net(x), y)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), {n: p.grad.detach().double().cpu() for n, p in net.named_parameters()}
+
+    two, one = run(False, dtype), run(True, dtype)
+    assert two[0] == one[0]
+    floor = run(False, torch.float32)[1] if dtype == torch.bfloat16 else None
+    bad = []
+    for n, g in two[1].items():
+        den = max(g.norm().item(), 1e-30)
+        err = (one[1][n] - g).norm().item()
+        allowed = 2e-5 * den if floor is None else 0.25 * (g - floor[n]).norm().item() + 1e-3 * den
+        if err > allowed:
+            bad.append((n, err / den, allowed / den))
+    assert not bad, bad[:8]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
