@@ -277,7 +277,7 @@ WGRAD_FILL_ALONE = float(os.environ.get("INSAR_WGRAD_FILL_ALONE", "1.0"))   # ..
 WGRAD_FILL = float(os.environ.get("INSAR_WGRAD_FILL", "0.5"))     # share of the work-group slots a side-stream weight gradient aims at
 WGRAD_ROWS = os.environ.get("INSAR_WGRAD_ROWS", "1") != "0"      # diagnostic: 0 = per-tap weight-gradient kernel everywhere
 FLAT_PP = int(os.environ.get("INSAR_FLAT_PP", "1"))               # flat 3x3 kernel: ping-pong tap steps (0 = plain loop; bitwise equal)
-FLAT_PERSIST = int(os.environ.get("INSAR_FLAT_PERSIST", "1"))     # flat 3x3 kernel: one work-group per CU walking its tiles (bitwise equal): 1 = forward launches, 2 = all, 0 = off
+FLAT_PERSIST = int(os.environ.get("INSAR_FLAT_PERSIST", "2"))     # flat 3x3 kernel: one work-group per CU walking its tiles (bitwise equal): 1 = forward launches, 2 = all (default since round 3: with the BatchNorm-backward sums carried over a work-group's tiles the input-gradient launches gain too, same-box 7.55 -> 7.49 ms/step), 0 = off
 IGEMM_PP = int(os.environ.get("INSAR_IGEMM_PP", "1"))            # 256 x 256 tiles: ping-pong K loop (0 = the plain two-slab loop; bitwise equal)
 BSTAT_FUSE = os.environ.get("INSAR_BSTAT_FUSE", "1") != "0"      # diagnostic: 0 = BatchNorm-backward sums always in a pass of their own
 WGRAD_LATE = os.environ.get("INSAR_WGRAD_ORDER", "before") == "after"      # diagnostic / tuning switch, see ConvBN.backward
@@ -323,9 +323,9 @@ def _igemm(x: Act, y: Act, w, N: int, Ho: int, Wo: int, stride: int, taps, mode:
 
 
 def _flat_persist(flip: int) -> bool:
-    """Persistent work-groups for the flat kernel: 1 = forward launches only (default: the input-gradient launches share
-    the chip with the side stream's weight gradients, where a static tile assignment loses to the dispatcher's; same-box
-    A/B in DESIGN.md), 2 = every launch, 0 = never."""
+    """Persistent work-groups for the flat kernel: 2 = every launch (default), 1 = forward launches only (round 2's default:
+    beside the side stream's weight gradients a static tile assignment then lost what it gained; since the input-gradient
+    launches also carry the consumer's BatchNorm-backward sums over their tiles it wins there too), 0 = never."""
     return FLAT_PERSIST == 2 or (FLAT_PERSIST == 1 and not (flip & 1))
 
 

@@ -117,8 +117,17 @@ def test_plan_launch_sequence(mocked_abi):
     assert c["insar_bn_relu_apply_pool_arg"] == 4 and c.get("insar_maxpool2_bwd", 0) == 0
     assert c["insar_bnrelu_bwd_reduce_pool"] == 4 and c["insar_bnrelu_bwd_apply_pool"] == 4
     # the unit that feeds outc recomputes its incoming gradient from dlogits; outc only produces its parameter gradients
-    # coefficient stages: one launch for the nine units without an SE gate, two for the nine with one
-    assert c["insar_bnse_bwd_coef"] == 9 and c["insar_bnse_bwd_coef_fused"] == 9 and c["insar_bnrelu_bwd_apply"] == 13 and c["insar_bnrelu_bwd_apply_outc"] == 1
+    # coefficients: the channel-parallel one-launch kernel for the nine units without an SE gate, two stages for the nine with one
+    assert c["insar_bnse_bwd_coef"] == 9 and c["insar_bn_bwd_coef"] == 9 and c.get("insar_bnse_bwd_coef_fused", 0) == 0
+    assert c["insar_bnrelu_bwd_apply"] == 13 and c["insar_bnrelu_bwd_apply_outc"] == 1
+    # BatchNorm-backward sums from the epilogue of the GEMM that produces the incoming gradient (InsarBstat): all nine first
+    # units of a block (no SE gate: any row partition), and of the four SE units fed by a transposed conv's input gradient
+    # the one whose 128-row GEMM tiles stay inside an image (16 x 16 pixels here; 4, 16 and 64 pixels do not): 3 plain
+    # reduce passes are left, + the 4 bias reductions of the transposed convs on the same entry point
+    plan0 = net._plan(x)
+    fused = [u.name for b in plan0.enc + plan0.dconv for u in (b.u1, b.u2) if u.bred is not None]
+    assert len(fused) == 10 and "conv3.3" in fused and all(n.endswith(".0") for n in fused if n != "conv3.3"), fused
+    assert c["insar_bnrelu_bwd_reduce"] == 3 + 4
     # ... and those come out of the same reduce pass (one read of y), folded by a column sum: no pass of their own
     assert c["insar_bnrelu_bwd_reduce_outc"] == 1 and c.get("insar_conv1x1_out_wgrad_y", 0) == 0 and c.get("insar_conv1x1_out_bwd", 0) == 0
     # ... and in forward its BN/ReLU/gate pass writes the logits itself (no 64-channel output tensor, no separate outc launch)
