@@ -289,7 +289,7 @@ def measure(args, world: int, rank: int, dev, dist, iu, engine, make_batch):
                         tj = json.load(open(tpath))
                     except Exception:
                         continue
-                    stem = dom_tag.rstrip(">")          # the profiler's name carries further template arguments
+                    stem = dom_tag.split(" +")[0].rstrip(">")          # the profiler's name carries further template arguments
                     hit = [v for k, v in tj.items() if k.startswith(stem) and isinstance(v, dict) and "hbm_bytes_per_launch" in v]
                     if hit:
                         traffic = hit[0]["hbm_bytes_per_launch"]
@@ -333,6 +333,11 @@ def measure(args, world: int, rank: int, dev, dist, iu, engine, make_batch):
             out["gemm_total"] = total(summ, t_el)
             out["gemm_kernels_alone"] = table(alone, timers["alone"].elapsed)
             out["gemm_total_alone"] = total(alone, timers["alone"].elapsed)
+            plain = {k: v for k, v in alone.items() if "+bstat" not in k}
+            if len(plain) != len(alone):
+                # launches tagged "+bstat" also do a BatchNorm-backward reduce pass's work in their epilogue (they read the
+                # consumer unit's y and fold two sums per channel: InsarBstat); the same kernels without it:
+                out["gemm_total_alone_plain_launches"] = total(plain, timers["alone"].elapsed)
         return out
     return None
 

@@ -496,7 +496,8 @@ static inline int igemm_bn_for(long long M, int N) {
 // (same-box A/B: the launches concerned 87.5 -> 80.7 us on average, the step 9.12 -> 8.98 ms); only where they still
 // give every CU a work-group.
 static inline bool igemm_xwide(long long M, int N, int dtype) {
-  return dtype == INSAR_BF16 && igemm_bm_for(M, N) == 256 && (N % 256) == 0 && ((M + 255) / 256) * (N / 256) >= 256;
+  const int min_tiles = insar_knob(KNOB_IGEMM_XWIDE_MIN) > 0 ? insar_knob(KNOB_IGEMM_XWIDE_MIN) : 256;
+  return dtype == INSAR_BF16 && igemm_bm_for(M, N) == 256 && (N % 256) == 0 && ((M + 255) / 256) * (N / 256) >= min_tiles;
 }
 extern "C" int insar_igemm_tile_cols_dt(int64_t M, int32_t N, int32_t dtype) {
   return igemm_xwide(M, N, dtype) ? 256 : igemm_bn_for(M, N);

@@ -280,6 +280,7 @@ FLAT_PP = int(os.environ.get("INSAR_FLAT_PP", "1"))               # flat 3x3 ker
 FLAT_PERSIST = int(os.environ.get("INSAR_FLAT_PERSIST", "2"))     # flat 3x3 kernel: one work-group per CU walking its tiles (bitwise equal): 1 = forward launches, 2 = all (default since round 3: with the BatchNorm-backward sums carried over a work-group's tiles the input-gradient launches gain too, same-box 7.55 -> 7.49 ms/step), 0 = off
 IGEMM_PP = int(os.environ.get("INSAR_IGEMM_PP", "1"))            # 256 x 256 tiles: ping-pong K loop (0 = the plain two-slab loop; bitwise equal)
 BSTAT_FUSE = os.environ.get("INSAR_BSTAT_FUSE", "1") != "0"      # diagnostic: 0 = BatchNorm-backward sums always in a pass of their own
+BSTAT_C64 = os.environ.get("INSAR_BSTAT_C64", "1") != "0"       # the 64 -> 64 kernel's variant of it. Alone it costs more than it saves (8-byte y loads from the accumulator layout: 89 -> 140 us per launch against the 43 us reduce pass it replaces), in the step it wins (same-box A/B 7.70 -> 7.61 ms: one launch less on the dgrad chain beside the weight-gradient stream)
 WGRAD_LATE = os.environ.get("INSAR_WGRAD_ORDER", "before") == "after"      # diagnostic / tuning switch, see ConvBN.backward
 
 
@@ -313,8 +314,9 @@ def _igemm(x: Act, y: Act, w, N: int, Ho: int, Wo: int, stride: int, taps, mode:
         bn = call("insar_igemm_tile_cols_dt", x.B * Ho * Wo, N, x.code)
         if oob and x.code == _lib.F32:
             bn = 64                       # fp32 out-of-bounds variants: 64-column tiles only
-        tag = "igemm_kernel<%s, %d, %d, %d%s>" % ("float" if x.code == _lib.F32 else "bf16_t", bm, bn,
-                                                  3 if bm == 256 and bn < 256 else 2, ", oob" if oob else "")
+        tag = "igemm_kernel<%s, %d, %d, %d%s>%s" % ("float" if x.code == _lib.F32 else "bf16_t", bm, bn,
+                                                    3 if bm == 256 and bn < 256 else 2, ", oob" if oob else "",
+                                                    " +bstat" if bstat is not None else "")
         es = 2 if x.code == _lib.BF16 else 4      # operands each read once, output written once
         nbytes = es * (x.B * x.H * x.W * x.c_len + y.B * y.H * y.W * y.c_len + len(taps) * N * x.c_len)
         PROFILER.run(tag, flops, lambda: call("insar_igemm", C.byref(d), _lib.stream_ptr()), nbytes)
@@ -338,7 +340,8 @@ def _conv3x3_flat(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[to
         fn = lambda: call("insar_conv3x3_flat", x.ref, y.ref, ptr(w), flags, ptr(stats), _lib.stream_ptr())
     if PROFILER is not None:
         flops = 2.0 * x.B * x.H * x.W * y.c_len * x.c_len * 9
-        tag = "conv3x3_flat_kernel<%s, %d>" % ("float" if x.code == _lib.F32 else "bf16_t", 128 if y.c_len % 128 == 0 else 64)
+        tag = "conv3x3_flat_kernel<%s, %d>%s" % ("float" if x.code == _lib.F32 else "bf16_t", 128 if y.c_len % 128 == 0 else 64,
+                                                 " +bstat" if bstat is not None else "")
         PROFILER.run(tag, flops, fn)
         return
     fn()
@@ -351,7 +354,7 @@ def _conv3x3_c64(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[tor
     else:
         fn = lambda: call("insar_conv3x3_c64", x.ref, y.ref, ptr(w), flip, ptr(stats), _lib.stream_ptr())
     if PROFILER is not None:
-        PROFILER.run("conv3x3_c64_kernel<2>", 2.0 * x.B * x.H * x.W * 64 * 64 * 9, fn)
+        PROFILER.run("conv3x3_c64_kernel<2>" + (" +bstat" if bstat is not None else ""), 2.0 * x.B * x.H * x.W * 64 * 64 * 9, fn)
         return
     fn()
 
@@ -744,7 +747,7 @@ class ConvBN:
                 raise _lib.InsarError(f"{self.name}: input gradient of the direct first-layer conv is not provided")
             if self.c64_bwd:
                 slab = None
-                if bstat_for is not None and BSTAT_FUSE and not bstat_se and _same_layout(dx, bstat_for.y):
+                if bstat_for is not None and BSTAT_FUSE and BSTAT_C64 and not bstat_se and _same_layout(dx, bstat_for.y):
                     slab = bstat_for.bstat_slab(call("insar_conv3x3_c64_rows", self.dy.ref), False)
                 if slab:
                     _conv3x3_c64(self.dy, dx, self.w.dgrad(), 1, slab[0], bstat=slab[1])

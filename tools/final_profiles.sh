@@ -34,9 +34,23 @@ cp $(ls "$OUT"/pT/*/*_kernel_trace.csv | head -n 1) "$OUT/kernel_trace.csv"
 python3 "$R/tools/pmc_traffic.py" "$OUT/pmc_fetch.csv" "$OUT/pmc_write.csv" "$OUT/pmc_traffic.json" "timed region (weight gradients split for half the work-group slots, as beside the dgrad chain)" | tee "$OUT/pmc_traffic.txt"
 python3 "$R/tools/timeline.py" "$OUT/kernel_trace.csv" | tee "$OUT/timeline.txt"
 rm -rf "$OUT/p1" "$OUT/p2" "$OUT/p3" "$OUT/pF" "$OUT/pW" "$OUT/pT" "$OUT/pmc_fetch.csv" "$OUT/pmc_write.csv"      # keep the summaries only
+echo "== SQ counters (one PMC pass, single stream: every kernel alone on the chip)"
+INSAR_SIDE_STREAM=0 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/pS" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/pS.log" 2>&1 && python3 "$R/tools/sq_counters.py" $(ls "$OUT"/pS/*/*_counter_collection.csv | head -n 1) 1e8 | tee "$OUT/pmc_sq_counters.txt"
+rm -rf "$OUT/pS"
+echo "== in-kernel stamps (diagnostic build of the library)"
+if [ -f "$R/insar_unet_ca_amd/libinsar_hip_stamps.so" ]; then
+  INSAR_HIP_LIB=$R/insar_unet_ca_amd/libinsar_hip_stamps.so timeout -k 10 200 python3 "$R/tools/stamp_gemm.py" 2>/dev/null | tee "$OUT/stamps_gemm.txt"
+  INSAR_HIP_LIB=$R/insar_unet_ca_amd/libinsar_hip_stamps.so timeout -k 10 200 python3 "$R/tools/stamp_flat.py" 2>/dev/null | tee "$OUT/stamps_flat.txt"
+fi
+echo "== stream-input vs resident"
+pick='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], d["ms_per_step"], d["value"])'
+for i in 1 2; do
+  timeout -k 10 150 python3 "$R/bench.py" --steps 40 --warmup 10 --no-cpu-baseline --no-kernel-timing --no-other-configs 2>/dev/null | python3 -c "$pick" resident | tee -a "$OUT/stream_input.txt"
+  timeout -k 10 150 python3 "$R/bench.py" --steps 40 --warmup 10 --no-cpu-baseline --no-kernel-timing --no-other-configs --stream-input 2>/dev/null | python3 -c "$pick" streamed | tee -a "$OUT/stream_input.txt"
+done
 echo "== hipGraph replay vs eager launches"
-timeout -k 10 300 python3 "$R/bench.py" --graph on --no-cpu-baseline --no-kernel-timing --steps 30 --warmup 5 > "$OUT/bench_graph.json" 2> "$OUT/bench_graph.err"; cut -c1-200 "$OUT/bench_graph.json"
-timeout -k 10 300 python3 "$R/bench.py" --graph off --no-cpu-baseline --no-kernel-timing --steps 30 --warmup 5 > "$OUT/bench_eager.json" 2> "$OUT/bench_eager.err"; cut -c1-200 "$OUT/bench_eager.json"
+timeout -k 10 300 python3 "$R/bench.py" --graph on --no-cpu-baseline --no-kernel-timing --no-other-configs --steps 30 --warmup 5 > "$OUT/bench_graph.json" 2> "$OUT/bench_graph.err"; cut -c1-200 "$OUT/bench_graph.json"
+timeout -k 10 300 python3 "$R/bench.py" --graph off --no-cpu-baseline --no-kernel-timing --no-other-configs --steps 30 --warmup 5 > "$OUT/bench_eager.json" 2> "$OUT/bench_eager.err"; cut -c1-200 "$OUT/bench_eager.json"
 echo "== microbench: ping-pong K loop, same-process A/B"
 timeout -k 10 300 python3 "$R/tools/gemm_bench.py" --only down2.3,conv2.0,conv1.0 --what pp 2>/dev/null | tee "$OUT/gemm_pingpong_ab.txt"
 echo "== 2-rank rehearsal (gloo, both ranks on the one GPU: exercises the bucketed reducer inside backward)"
