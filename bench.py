@@ -101,6 +101,9 @@ def measure(args, world: int, rank: int, dev, dist, iu, engine, make_batch):
         opt = ShardedAdam(model, lr=1e-4, defer_gather=True)
     else:
         opt = iu.Adam(net.parameters(), lr=1e-4)
+    adam_fused = world == 1 and args.adam_in_backward == "on" and args.graph != "on"
+    if adam_fused:
+        opt.fuse_into_backward(net)
 
     # synthetic tiles, resident in HBM before timing; every rank draws different tiles
     nb = 2
@@ -239,7 +242,9 @@ def measure(args, world: int, rank: int, dev, dist, iu, engine, make_batch):
             "config": {"workload": f"{name} {args.dtype}, batch {args.batch}x{channels}x{args.size}x{args.size} "
                                    f"per GPU, {'Dice+CE' if args.loss == 'dice_ce' else 'CE'} + Adam(lr=1e-4) training on synthetic InSAR tiles",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
-            "final_loss": round(final_loss, 5), "hipgraph": bool(use_graph), "input": "streamed from pinned host memory (copy stream, one batch ahead)" if args.stream_input else "resident in HBM",
+            "final_loss": round(final_loss, 5), "hipgraph": bool(use_graph),
+            "optimizer": ("Adam(lr=1e-4), update + weight re-layout issued stage by stage inside backward on the side stream "
+                          "(Adam.fuse_into_backward; bitwise the plain step)" if adam_fused else "Adam(lr=1e-4), optimizer.step() after backward"), "input": "streamed from pinned host memory (copy stream, one batch ahead)" if args.stream_input else "resident in HBM",
             "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 3),
             "hbm_allocated_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
         }
@@ -383,6 +388,11 @@ def main() -> int:
     ap.add_argument("--graph", default="off", choices=["auto", "on", "off"],
                     help="replay the step from a captured hipGraph (insar_unet_ca_amd.GraphedTrainStep): off by default (measured slower than eager launches on ROCm 7.2: 8.6 vs 7.9 ms/step); auto = on for 1 GPU, off "
                          "under data parallelism (the RCCL collectives inside backward are issued eagerly)")
+    ap.add_argument("--adam-in-backward", default="off", choices=["on", "off"],
+                    help="1 GPU: Adam.fuse_into_backward — the optimizer update and the weight re-layout of a backward stage run on the "
+                         "side stream as soon as the stage's gradients are enqueued (same arithmetic, bitwise the plain step). Measured "
+                         "SLOWER (7.77 -> 8.29 ms/step: 875 MB of optimizer traffic beside the dgrad chain costs more than the 0.17 ms "
+                         "it hides), so off by default: optimizer.step() after backward does all of it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",

@@ -206,6 +206,19 @@ class WeightSet:
         self._jobs = None
         self._ptrs = None
         self._total = 0
+        self._by_stage = None
+
+    def stage_sets(self, groups) -> List["WeightSet"]:
+        """One WeightSet per backward stage (the GEMM weights whose master parameter belongs to that stage): an optimizer
+        that runs stage by stage inside backward (optim.Adam.fuse_into_backward) re-lays a stage's weights right behind its
+        update, and the next forward finds nothing stale."""
+        if self._by_stage is None:
+            owner = {id(p): i for i, g in enumerate(groups) for p in g}
+            buckets = [[] for _ in groups]
+            for w in self.weights:
+                buckets[owner[id(w.param)]].append(w)
+            self._by_stage = [WeightSet(self.ctx, b) if b else None for b in buckets]
+        return self._by_stage
 
     def refresh(self) -> None:
         stale = [w for w in self.weights if w._key["fwd"] != w.key() or w._key["dgrad"] != w.key()]
@@ -443,6 +456,7 @@ class GradSink:
         if groups is None:
             groups = [list(params)]
         self.params = [p for g in groups for p in g]
+        self.groups = [list(g) for g in groups]         # parameters per backward stage, in completion order
         offs, self.group_sizes, total = flat_layout(groups)
         self.flats = [torch.zeros(total, dtype=torch.float32, device=ctx.device) for _ in range(2)]
         self.views = [{id(p): f[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, offs)} for f in self.flats]

@@ -421,7 +421,18 @@ class _UNetFn(torch.autograd.Function):
         hooks = ctx.hooks or {}
         if hooks.get("on_begin"):
             hooks["on_begin"](plan)
-        grads = plan.backward(dlogits, on_bucket=hooks.get("on_bucket"))
+        on_bucket = hooks.get("on_bucket")
+        early = hooks.get("on_stage_optim")
+        if early is not None and on_bucket is None:
+            # optimizer fused into backward (optim.Adam.fuse_into_backward): after every backward stage its parameters are
+            # updated and re-laid out on the side stream. Not under data parallelism (the gradients are not final yet there).
+            stage = [0]
+            early(plan, -1)
+
+            def on_bucket(pl, tag):
+                early(pl, stage[0])
+                stage[0] += 1
+        grads = plan.backward(dlogits, on_bucket=on_bucket)
         if hooks.get("on_done"):
             hooks["on_done"](plan)
         if ctx.lease:

@@ -24,6 +24,9 @@ class Adam(torch.optim.Adam):
         self._dev_pending = 0      # steps taken on the device that state['step'] has not been told about yet
         self._fast = None          # (params, grads, step tensors, table, chunks, nchunks) of the last full step
         self.generation = 0        # bumped whenever optimizer state had to be re-allocated (see load_state_dict)
+        self._early_tables = {}    # (plan id, stage, gradient buffer) -> (table, chunks, nchunks, params)
+        self._early_done = set()   # ids of the parameters already updated inside the current backward
+        self._early_stages = 0
 
     # ---- device-side step count (hipGraph capture) ---------------------------------------------------------
     def enable_device_step(self) -> None:
@@ -46,6 +49,87 @@ class Adam(torch.optim.Adam):
         t = steps.pop() if steps else 0.0
         b1, b2 = self.param_groups[0]["betas"]
         self._dev_state = torch.tensor([t, 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t), 0.0], dtype=torch.float32).to(dev)
+
+    # ---- optimizer inside backward ------------------------------------------------------------------------
+    def fuse_into_backward(self, model) -> "Adam":
+        """Run this optimizer STAGE BY STAGE inside `loss.backward()`: as soon as a backward stage of `model` (a decoder /
+        encoder block: engine.grad_groups) has enqueued its last gradient kernel, Adam updates that stage's parameters on the
+        weight-gradient side stream and the stage's GEMM-layout weight copies are rebuilt right behind it — beside the rest of
+        backward instead of after it (the reference's loop runs optimizer.step() after loss.backward(), :345-346; same
+        arithmetic, same order per parameter, so the parameters are bit for bit those of the plain step). `step()` then only
+        finishes what is left (nothing, in the steady state) and advances the step counts.
+        MEASURED SLOWER on config 2 (same-box A/B 7.77 -> 8.29 ms/step, profiles/r03_adam_in_backward_ab.txt: 875 MB of optimizer
+        traffic and 18 extra launches beside the dgrad chain cost more than the 0.17 ms of exposed Adam they hide), so nothing
+        in this repository turns it on; it stays as a tested option for steps with a different balance.
+        Contract of the opt-in: ONE backward per step() (no gradient accumulation over several backward calls: a second
+        backward before step() raises), nobody reads the parameters between backward and step(), one parameter group, no
+        data-parallel wrapper (there the gradients are final only after the exchange; the plain step is used)."""
+        hooks = getattr(model, "_hooks", None)
+        if hooks is None:
+            raise _lib.InsarError("Adam.fuse_into_backward: the model has no HIP plan hooks (UNet / DeepLabV3_SingleChannel_Attn)")
+        hooks["on_stage_optim"] = self._early_stage
+        return self
+
+    def _early_stage(self, plan, stage: int) -> None:
+        if stage < 0:                            # backward begins
+            if self._early_done:
+                raise _lib.InsarError("Adam.fuse_into_backward: a second backward before optimizer.step() — the first one has "
+                                      "already updated parameters; gradient accumulation needs the plain step")
+            self._early_stages = 0
+            return
+        f = self._fast
+        if (f is None or self._dev_state is not None or len(self.param_groups) != 1 or torch.cuda.is_current_stream_capturing()
+                or stage >= len(plan.sink.groups)):
+            return                               # not in the steady state yet (first steps build the optimizer state): plain step()
+        from . import engine
+        group = self.param_groups[0]
+        key = (id(plan), stage, plan.sink.active)
+        hit = self._early_tables.get(key)
+        if hit is None:
+            params = plan.sink.groups[stage]
+            tensors = []
+            for p in params:
+                st = self.state.get(p)
+                if not p.requires_grad or st is None or "exp_avg" not in st:
+                    return
+                tensors.append((p, plan.sink.view(p), st["exp_avg"], st["exp_avg_sq"]))
+            if not tensors:
+                return
+            table, chunk_t, nchunks = self._table(("early",) + key, tensors)
+            if len(self._early_tables) > 64:
+                self._early_tables.clear()
+            hit = self._early_tables[key] = (table, chunk_t, nchunks, [t[0] for t in tensors])
+        table, chunk_t, nchunks, params = hit
+        b1, b2 = group["betas"]
+        t = float(self.state[params[0]]["step"]) + 1.0
+        with plan.ctx.side_stream():             # ordered after everything this stage has enqueued on either stream
+            call("insar_adam_step", ptr(table), ptr(chunk_t), nchunks, CHUNK, float(group["lr"]), float(b1), float(b2),
+                 float(group["eps"]), 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t), float(self.grad_scale), _lib.stream_ptr())
+            torch._C._increment_version(params)
+            ws = plan.weightset.stage_sets(plan.sink.groups)[stage]
+            if ws is not None and engine.PREP_SIDE:
+                ws.refresh()                     # this stage's GEMM-layout copies: the next forward finds them current
+        self._early_done.update(id(p) for p in params)
+        self._early_stages += 1
+
+    def _finish_early(self) -> bool:
+        """step() after a backward that ran (some of) the update itself. True if nothing is left to do."""
+        done, self._early_done = self._early_done, set()
+        group = self.param_groups[0]
+        rest = [p for p in group["params"] if p.grad is not None and id(p) not in done]
+        b1, b2 = group["betas"]
+        t = float(self.state[group["params"][0]]["step"]) + 1.0
+        if rest:                                 # stages that did not take part (a plan change mid-way): the same kernel on them
+            tensors = [(p, p.grad, self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"]) for p in rest]
+            table, chunk_t, nchunks = self._table(tuple(x.data_ptr() for tup in tensors for x in tup), tensors)
+            call("insar_adam_step", ptr(table), ptr(chunk_t), nchunks, CHUNK, float(group["lr"]), float(b1), float(b2),
+                 float(group["eps"]), 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t), float(self.grad_scale), _lib.stream_ptr())
+            torch._C._increment_version(rest)
+        for p in group["params"]:
+            st = self.state.get(p)
+            if st is not None and "step" in st and (p.grad is not None or id(p) in done):
+                st["step"] += 1
+        return True
 
     def _sync_host_steps(self) -> None:
         if self._dev_pending:
@@ -85,6 +169,7 @@ class Adam(torch.optim.Adam):
         if not in_place:
             self._fast = None
             self._tables.clear()
+            self._early_tables.clear()
             self.generation += 1
         if self._dev_state is not None:
             self._dev_pending = 0
@@ -143,6 +228,9 @@ class Adam(torch.optim.Adam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if closure is None and self._early_done:
+            self._finish_early()
+            return loss
         if closure is None and self._fast_step():
             if self._dev_state is not None:
                 self._dev_pending += 1
