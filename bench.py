@@ -167,6 +167,15 @@ def measure(args, world: int, rank: int, dev, dist, iu, engine, make_batch):
             timed_step(i)
         torch.cuda.synchronize()
 
+    # the host's own cost of enqueuing a step: three steps into an EMPTY queue (over a whole run the enqueue time also contains
+    # the back-pressure of a full command queue, i.e. GPU time: host_enqueue_ms_per_step below saturates at about the GPU time
+    # minus ten steps' worth of queue)
+    torch.cuda.synchronize()
+    th = time.perf_counter()
+    for i in range(3):
+        timed_step(i)
+    host_unblocked = (time.perf_counter() - th) / 3
+    torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
         model.exposed_events.clear()
@@ -246,8 +255,14 @@ def measure(args, world: int, rank: int, dev, dist, iu, engine, make_batch):
             "optimizer": ("Adam(lr=1e-4), update + weight re-layout issued stage by stage inside backward on the side stream "
                           "(Adam.fuse_into_backward; bitwise the plain step)" if adam_fused else "Adam(lr=1e-4), optimizer.step() after backward"), "input": "streamed from pinned host memory (copy stream, one batch ahead)" if args.stream_input else "resident in HBM",
             "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 3),
+            "host_ms_per_step_empty_queue": round(1e3 * host_unblocked, 3),
             "hbm_allocated_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
         }
+        try:        # launch tapes (insar_unet_ca_amd/tape.py): which of the plan's passes were replayed from a recorded launch list
+            plans = [pl for lst in net._plans.plans.values() for pl in lst]
+            out["launch_tape"] = {str(k): v for pl in plans for k, v in pl.tape_report().items()}
+        except Exception as e:      # noqa: BLE001 - reporting only
+            out["launch_tape"] = f"unavailable: {e}"
         if dp_info is not None:
             out.update(dp_info)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS

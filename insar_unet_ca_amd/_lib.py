@@ -217,14 +217,20 @@ _COUNT_ONLY = {"insar_tune_get", "insar_igemm_num_mtiles", "insar_igemm_tile_row
                "insar_ce_blocks", "insar_conv7x7s2_fwd_rows", "insar_conv7x7s2_wgrad_blocks"}
 
 
+_TAPE = None      # while a launch tape is being recorded (tape.py): the list every launch is appended to
+
+
 def call(name: str, *args) -> int:
     """Invoke an entry point; negative return codes raise InsarError(insar_last_error())."""
     lib = load()
-    rc = getattr(lib, name)(*args)
+    fn = getattr(lib, name)
+    rc = fn(*args)
     if name in _COUNT_ONLY:
         return rc
     if rc != 0:
         raise InsarError(f"{name} failed ({rc}): {lib.insar_last_error().decode(errors='replace')}")
+    if _TAPE is not None:
+        _TAPE.append((fn, args, name))
     return 0
 
 

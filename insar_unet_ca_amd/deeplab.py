@@ -21,7 +21,8 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
-from . import _lib, engine
+from . import _lib, engine, tape
+from .tape import tape_py
 from ._lib import InsarBnFinalize, InsarBnSeBwd, InsarCam, InsarWgrad, call, ptr
 from .engine import Act, Ctx, GemmWeight, GradSink, OutConvPlan, WeightSet, _igemm, _round_up, _rows_per_part, _wgrad_nsplit
 from .modules import ChannelAttentionModule, _PlanCache, _UNetFn, _require_device, _resolve_dtype
@@ -353,7 +354,7 @@ class ConvUnit:
                     idx = torch.tensor([self.tap_ids[i] for i, _ in sel], dtype=torch.int64, device=self.ctx.device)
                     self._class_w[key] = (idx, torch.empty((len(sel),) + tuple(wd.shape[1:]), dtype=wd.dtype, device=wd.device))
                 idx, buf = self._class_w[key]
-                torch.index_select(wd, 0, idx, out=buf)
+                tape_py(lambda wd=wd, idx=idx, buf=buf: torch.index_select(wd, 0, idx, out=buf))
                 taps = [((py - t[0]) // 2, (px - t[1]) // 2) for _, t in sel]
                 _igemm(self.dy, dx, buf, self.cin, hc, wc, 1, taps, 0, add=add, out_stride=2, out_off=(py, px))
 
@@ -384,8 +385,8 @@ class ConvUnit:
             if self._tmp_grad is None:
                 self._tmp_grad = ctx.f32(self.cout, self.cin)
             ctx.wgrad_finish(part, self._tmp_grad, nsplit, 1, self.cout, self.cin, 0)
-            gw.zero_()
-            gw[:, :, 1, 1].copy_(self._tmp_grad)
+            centre, tmp = gw[:, :, 1, 1], self._tmp_grad
+            tape_py(lambda: (gw.zero_(), centre.copy_(tmp)))
         else:
             ctx.wgrad_finish(part, gw, nsplit, nt, self.cout, self.cin, 0)
 
@@ -443,7 +444,7 @@ class BottleneckPlan:
             self.ud.backward(g, sink, training, dx, relu=False, add=dx)
 
 
-class DeepLabPlan:
+class DeepLabPlan(tape.PlanTape):
     """Buffers + launch sequence of DeepLabV3_SingleChannel_Attn.forward / backward for one input geometry."""
 
     def __init__(self, net: DeepLabV3_SingleChannel_Attn, B: int, H: int, W: int, dtype: torch.dtype, device: torch.device):
@@ -546,6 +547,8 @@ class DeepLabPlan:
         self.units = units
         self.weightset = WeightSet(ctx, [u.w for u in units])
         self.bn_modules = [self.stem_bn] + [u.bn for u in units]
+        self._logits_lo = self._dlo = None
+        self._tape_setup()
         self.busy = False
         self.training = True
         self.x_in: Optional[torch.Tensor] = None
@@ -574,12 +577,30 @@ class DeepLabPlan:
         return d
 
     # ---- forward (DeepLabV3-ChannelAttention.py:140-162) -------------------------------------------------------
+    def _tape_key(self, which: str) -> tuple:
+        return super()._tape_key(which) + (self.drop_p,)
+
     def forward(self, x: torch.Tensor, training: bool) -> torch.Tensor:
+        """The ordinary launch sequence (_forward_eager) or, in the steady state of a training loop, its launch tape (tape.py)."""
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        if not self._tape_allowed(training, not self.external_mask):
+            return self._forward_eager(x, training)
+        logits = torch.empty((self.B, self.K, self.H, self.W), dtype=torch.float32, device=self.ctx.device)
+        out, replayed = self._run(self._tape_key("f"), lambda: self._forward_eager(x, training),
+                                  {"x": x.data_ptr(), "logits": logits.data_ptr()}, {x.data_ptr(): "x"},
+                                  dyn_after=lambda o: {o.data_ptr(): "logits"})
+        if replayed:
+            self.training = training
+            self.x_in = x.detach()                 # the stem's weight gradient reads it in backward
+            self.drop_active = training and self.drop_p > 0.0
+            return logits
+        return out
+
+    def _forward_eager(self, x: torch.Tensor, training: bool) -> torch.Tensor:
         s = _lib.stream_ptr()
         ctx = self.ctx
         self.training = training
-        if x.dtype != torch.float32 or not x.is_contiguous():
-            x = x.float().contiguous()
         self.x_in = x.detach()
         with ctx.side_stream():
             self.weightset.refresh()
@@ -616,7 +637,8 @@ class DeepLabPlan:
         if self.drop_active:
             # mask = hash(seed drawn once from torch's RNG, device-side forward counter, element index): a new mask every
             # training forward, also when the step is replayed from a captured hipGraph
-            self.drop_counter.add_(1)
+            ctr = self.drop_counter
+            tape_py(lambda: ctr.add_(1))
             call("insar_dropout", self.project.out.ref, self.zdrop.ref, ptr(self.drop_mask), self.drop_seed, ptr(self.drop_counter),
                  self.drop_p, 0 if self.external_mask else 1, s)
             self.head.x = self.zdrop
@@ -629,20 +651,35 @@ class DeepLabPlan:
         dcam = self._cam_desc()
         call("insar_cam_excite", C.byref(dcam), s)
         call("insar_bn_relu_apply", z.ref, ptr(self.ones), ptr(self.zeros), ptr(self.cam_gate), self.zc.ref, 0, s)
-        self.logits_lo = self.outc.forward()
+        if self._logits_lo is None:
+            self._logits_lo = torch.empty((self.B, self.K, z.H, z.W), dtype=torch.float32, device=ctx.device)
+        self.logits_lo = self.outc.forward(out=self._logits_lo)       # plan-owned (a launch tape holds its address)
         logits = torch.empty((self.B, self.K, self.H, self.W), dtype=torch.float32, device=ctx.device)
         call("insar_bilinear_fwd", ptr(self.logits_lo), ptr(logits), self.B * self.K, z.H, z.W, self.H, self.W, s)
         return logits
 
     # ---- backward ------------------------------------------------------------------------------------------------
     def backward(self, dlogits: torch.Tensor, on_bucket=None) -> List[torch.Tensor]:
-        s = _lib.stream_ptr()
-        ctx, sink, training = self.ctx, self.sink, self.training
+        """The ordinary launch sequence (_backward_eager) or its launch tape (tape.py)."""
         if dlogits.dtype != torch.float32 or not dlogits.is_contiguous():
             dlogits = dlogits.float().contiguous()
-        sink.select()
+        self.sink.select()
+        if not self._tape_allowed(self.training, on_bucket is None and not self.external_mask):
+            return self._backward_eager(dlogits, on_bucket)
+        xp = self.x_in.data_ptr()
+        out, replayed = self._run(self._tape_key("b"), lambda: self._backward_eager(dlogits, None),
+                                  {"dlogits": dlogits.data_ptr(), "x": xp}, {dlogits.data_ptr(): "dlogits", xp: "x"})
+        if replayed:
+            return [self.sink.view(p) for p in self.grad_params]
+        return out
+
+    def _backward_eager(self, dlogits: torch.Tensor, on_bucket=None) -> List[torch.Tensor]:
+        s = _lib.stream_ptr()
+        ctx, sink, training = self.ctx, self.sink, self.training
         z = self.head.out
-        dlo = torch.empty_like(self.logits_lo)
+        if self._dlo is None:
+            self._dlo = torch.empty_like(self.logits_lo)
+        dlo = self._dlo
         call("insar_bilinear_bwd", ptr(dlogits), ptr(dlo), self.B * self.K, z.H, z.W, self.H, self.W, s)
         dzc = self._grad("dzc", self.zc)
         self.outc.backward(dlo, sink, dzc)

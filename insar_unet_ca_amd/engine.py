@@ -15,8 +15,9 @@ from typing import Dict, List, Optional
 
 import torch
 
-from . import _lib
+from . import _lib, tape
 from ._lib import InsarAct, InsarBnFinalize, InsarBnSeBwd, InsarIgemm, InsarSeFwd, InsarWgrad, call, ptr
+from .tape import tape_py
 
 BN_ROW_PIX = 128        # igemm M-tile (rows of one stats slab row)
 WG_BKP = 64             # wgrad pixels per K step
@@ -89,14 +90,32 @@ class Ctx:
         if self.side is None or (PROFILER is not None and PROFILER.alone):
             yield
             return
-        self.side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.side):
+        prev = self._side_enter()
+        try:
             yield
+        finally:
+            self._side_exit(prev)
+
+    def _side_enter(self):
+        """(also what a launch tape replays) side stream waits for the current stream's position and becomes current"""
+        if tape.REC is not None:
+            tape.REC.op("side_enter")
+        prev = torch.cuda.current_stream()
+        self.side.wait_stream(prev)
+        torch.cuda.set_stream(self.side)
+        return prev
+
+    def _side_exit(self, prev) -> None:
+        torch.cuda.set_stream(prev)
         self._side_busy = True
+        if tape.REC is not None:
+            tape.REC.op("side_exit")
 
     def join_side(self) -> None:
         """Order the current stream after the side stream's work (end of backward, before a gradient bucket
         is handed to the all-reduce)."""
+        if tape.REC is not None:
+            tape.REC.op("join")
         if self._side_busy:
             torch.cuda.current_stream().wait_stream(self.side)
             self._side_busy = False
@@ -238,8 +257,11 @@ class WeightSet:
             self._jobs = torch.tensor(rows, dtype=torch.int64).to(self.ctx.device)
             self._ptrs, self._total = ptrs, tile0
         call("insar_weight_prep_pair_batch", ptr(self._jobs), self._jobs.shape[0], self._total, _lib.stream_ptr())
-        for w in self.weights:
-            w._key["fwd"] = w._key["dgrad"] = w.key()
+
+        def mark():         # (on a launch tape too: code that runs eagerly afterwards must find the copies current)
+            for w in self.weights:
+                w._key["fwd"] = w._key["dgrad"] = w.key()
+        tape_py(mark)
 
 
 class KernelTimer:
@@ -977,7 +999,8 @@ class UpPlan:
                     call("insar_bnrelu_bwd_reduce", dout.ref, dout.ref, ptr(ctx.const(0.0, self.cout)),
                          ptr(ctx.const(1.0, self.cout)), ptr(self.bias_part), 0, self.bias_rpp, _lib.stream_ptr())
                     ctx.colsum(self.bias_part, self.bias_sum, 1, self.bias_rows, 2 * self.cout)
-                    sink.view(self.mod.bias).copy_(self.bias_sum[0])
+                    dst_b, src_b = sink.view(self.mod.bias), self.bias_sum[0]
+                    tape_py(lambda: dst_b.copy_(src_b))
                 part = ctx.wgrad_part(nsplit * 4 * self.cout * self.cin)
                 d = InsarWgrad()
                 d.x, d.dy = x.desc, dout.desc
@@ -1018,19 +1041,19 @@ class OutConvPlan:
     def params(self):
         return [self.mod.weight, self.mod.bias]
 
-    def forward(self) -> torch.Tensor:
+    def forward(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         self.fused_src = None
         x = self.x
-        logits = torch.empty((x.B, self.K, x.H, x.W), dtype=torch.float32, device=self.ctx.device)
+        logits = out if out is not None else torch.empty((x.B, self.K, x.H, x.W), dtype=torch.float32, device=self.ctx.device)
         call("insar_conv1x1_out_fwd", x.ref, ptr(self.mod.weight),
              ptr(self.mod.bias) if self.mod.bias is not None else 0, ptr(logits), self.K, _lib.stream_ptr())
         return logits
 
-    def forward_fused(self, unit: "ConvBN", gate: Optional[torch.Tensor]) -> torch.Tensor:
+    def forward_fused(self, unit: "ConvBN", gate: Optional[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """logits straight from the last unit's raw conv output (its BN/ReLU/gate pass and outc in one launch; the
         unit's output activation is never written)."""
         y = unit.y
-        logits = torch.empty((y.B, self.K, y.H, y.W), dtype=torch.float32, device=self.ctx.device)
+        logits = out if out is not None else torch.empty((y.B, self.K, y.H, y.W), dtype=torch.float32, device=self.ctx.device)
         call("insar_bn_relu_apply_outc", y.ref, ptr(unit.scale), ptr(unit.shift), ptr(gate), ptr(self.mod.weight),
              ptr(self.mod.bias) if self.mod.bias is not None else 0, ptr(logits), self.K, 1, _lib.stream_ptr())
         self.fused_src = (unit, gate)
@@ -1042,9 +1065,11 @@ class OutConvPlan:
         def fold():
             self.ctx.colsum(self.part, self.folded, 1, self.nb, self.cols)
             kc = self.K * self.cin
-            sink.view(self.mod.weight).view(-1).copy_(self.folded[:kc])
+            dst_w, src_w = sink.view(self.mod.weight).view(-1), self.folded[:kc]
+            tape_py(lambda: dst_w.copy_(src_w))
             if self.mod.bias is not None:
-                sink.view(self.mod.bias).copy_(self.folded[kc:])
+                dst_b, src_b = sink.view(self.mod.bias), self.folded[kc:]
+                tape_py(lambda: dst_b.copy_(src_b))
 
         if dx is None and self.reduce_rows:
             # the parameter-gradient partials come out of the unit's BatchNorm-backward reduce pass (same read of y): only
@@ -1052,6 +1077,8 @@ class OutConvPlan:
             return
         if dx is None:
             if self.ctx.side is not None and not (PROFILER is not None and PROFILER.alone) and dlogits.is_cuda:
+                if tape.REC is not None:
+                    tape.REC.bad("record_stream on the caller's dlogits")      # this path is not replayable: stay eager
                 if torch.cuda.is_current_stream_capturing():
                     self._keep = dlogits                  # a graph's private pool: keep the buffer alive instead
                 else:
@@ -1088,9 +1115,11 @@ class OutConvPlan:
         with self.ctx.side_stream():
             self.ctx.colsum(self.part_red, self.folded, 1, self.reduce_rows, self.cols)
             kc = self.K * self.cin
-            sink.view(self.mod.weight).view(-1).copy_(self.folded[:kc])
+            dst_w, src_w = sink.view(self.mod.weight).view(-1), self.folded[:kc]
+            tape_py(lambda: dst_w.copy_(src_w))
             if self.mod.bias is not None:
-                sink.view(self.mod.bias).copy_(self.folded[kc:])
+                dst_b, src_b = sink.view(self.mod.bias), self.folded[kc:]
+                tape_py(lambda: dst_b.copy_(src_b))
 
     def virtual_grad_ok(self) -> bool:
         ch = 16 // self.ctx.esize
@@ -1110,7 +1139,7 @@ def unpack_output(src: Act) -> torch.Tensor:
     return out
 
 
-class UNetPlan:
+class UNetPlan(tape.PlanTape):
     """All buffers + the launch sequence of UNet.forward / backward for one input geometry."""
 
     def __init__(self, net, B: int, H: int, W: int, dtype: torch.dtype, device: torch.device):
@@ -1176,6 +1205,7 @@ class UNetPlan:
         gws += [u.w for u in self.up]
         self.weightset = WeightSet(ctx, gws)
         self.bn_modules = [u.bn for b in self.enc + self.dconv for u in (b.u1, b.u2)]
+        self._tape_setup()
 
     def bucket_closes(self, min_elems: int):
         if min_elems not in self._closes:
@@ -1185,6 +1215,28 @@ class UNetPlan:
 
     # ---- forward ----------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, training: bool) -> torch.Tensor:
+        """The ordinary launch sequence (_forward_eager) or, in the steady state of a training loop, its launch tape (tape.py)."""
+        if not (self._tape_allowed(training) and self.outc.virtual_grad_ok()):
+            return self._forward_eager(x, training)
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        logits = torch.empty((self.B, self.outc.K, self.H, self.W), dtype=torch.float32, device=self.ctx.device)
+        slots = {"x": x.data_ptr(), "logits": logits.data_ptr()}
+        box = {}
+
+        def eager():
+            box["out"] = self._forward_eager(x, training)
+            return box["out"]
+
+        # a recording's own logits tensor (allocated inside the eager code) becomes the "logits" slot of the tape
+        out, replayed = self._run(self._tape_key("f"), eager, slots, {x.data_ptr(): "x"},
+                                  dyn_after=lambda o: {o.data_ptr(): "logits"})
+        if replayed:
+            self.training = training
+            return logits
+        return out
+
+    def _forward_eager(self, x: torch.Tensor, training: bool) -> torch.Tensor:
         s = _lib.stream_ptr
         self.training = training
         # all GEMM-layout weight copies in one launch when the masters moved. The first layer works on the fp32
@@ -1210,11 +1262,21 @@ class UNetPlan:
 
     # ---- backward ---------------------------------------------------------------------------------
     def backward(self, dlogits: torch.Tensor, on_bucket=None) -> List[torch.Tensor]:
-        s = _lib.stream_ptr
+        """The ordinary launch sequence (_backward_eager) or its launch tape; data-parallel hooks keep the ordinary code."""
         if dlogits.dtype != torch.float32 or not dlogits.is_contiguous():
             dlogits = dlogits.float().contiguous()
+        self.sink.select()
+        if not (self._tape_allowed(self.training, on_bucket is None) and self.outc.virtual_grad_ok()):
+            return self._backward_eager(dlogits, on_bucket)
+        out, replayed = self._run(self._tape_key("b"), lambda: self._backward_eager(dlogits, None),
+                                  {"dlogits": dlogits.data_ptr()}, {dlogits.data_ptr(): "dlogits"})
+        if replayed:
+            return [self.sink.view(p) for p in self.grad_params]
+        return out
+
+    def _backward_eager(self, dlogits: torch.Tensor, on_bucket=None) -> List[torch.Tensor]:
+        s = _lib.stream_ptr
         sink, training, w = self.sink, self.training, self.widths
-        sink.select()
         fuse = self.outc.virtual_grad_ok()
         wg = self.outc.fused_grad(self.dconv[3].u2) if fuse else None
         self.outc.backward(dlogits, sink, None if fuse else self.ddec[0])
