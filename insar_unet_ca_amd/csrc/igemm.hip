@@ -487,7 +487,10 @@ static inline int igemm_bm_for(long long M, int N) {
 // per SIMD to hide each other's LDS and barrier latency).
 static inline int igemm_bn_for(long long M, int N) {
   if (N % 128) return 64;
-  if (igemm_bm_for(M, N) == 256) return ((M + 255) / 256) * (N / 128) >= 256 ? 128 : 64;
+  if (igemm_bm_for(M, N) == 256) {
+    const int min_tiles = insar_knob(KNOB_IGEMM_WIDE_MIN) > 0 ? insar_knob(KNOB_IGEMM_WIDE_MIN) : 256;
+    return ((M + 255) / 256) * (N / 128) >= min_tiles ? 128 : 64;
+  }
   const long long tiles = ((M + 127) / 128) * (N / 128);
   return tiles <= 256 ? 64 : 128;
 }
