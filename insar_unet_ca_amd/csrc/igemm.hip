@@ -79,7 +79,7 @@ struct IgemmCfg {
   static constexpr int MAIN = (NSTAGE * STAGE > TILE) ? NSTAGE * STAGE : TILE;
   static constexpr int ROWINFO = BM * 8 * 2 + BM * 4;      // rowIn[BM], rowOut[BM] (int64), rowHW[BM] (int32)
   static constexpr int STATB = NWAVES * BN * 2 * 4;        // per-wave channel partials
-  static constexpr int TAPB = 64 + 32;                      // tap offsets (12 ints), tap dy/dx (12 + 12 bytes)
+  static constexpr int TAPB = 64 + 32 + 128;                // tap offsets (12 ints), tap dy/dx (12 + 12 bytes), OOB: live flags / live-tap list (2 x 16 ints)
   static constexpr int LDS_BYTES = MAIN + ROWINFO + STATB + TAPB;
 };
 
@@ -145,12 +145,17 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
   const long long m0 = (long long)mtile * BM;
   const int n0 = ntile * BN;
 
+  int* slive = stap + 24;            // OOB: [0,12) live flag per tap, [12] number of live taps, [16, 28) the live taps in order
   if (tid == THREADS - 1) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) stap[i] = a.tapoff[i];
     signed char* sd = (signed char*)(stap + 16);
 #pragma unroll
     for (int i = 0; i < 12; ++i) { sd[i] = a.tdy[i]; sd[16 + i] = a.tdx[i]; }
+    if constexpr (OOB) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) slive[i] = 0;
+    }
   }
   if (tid < BM) {
     const long long m = m0 + tid;
@@ -168,6 +173,30 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
     rowHW[tid] = valid ? (((ho * a.stride + 1) << 16) | (wo * a.stride + 1)) : (0x4000 << 16);
   }
   __syncthreads();
+  if constexpr (OOB) {
+    // Taps that no row of this tile can reach inside the image (dilation 12 / 24 on a 32 x 32 map: a tile of 8 image rows
+    // sees the +-24 rows from one quarter of the map only) are dropped from the tile's K loop instead of being multiplied
+    // against the zero pixel: every row marks the taps it reaches (the halo counts as outside: it is zero), one thread
+    // compacts the list. Adding exact zeros is what is skipped: the sums are unchanged.
+    if (tid < BM) {
+      const int hw = rowHW[tid];
+      const int h0 = hw >> 16, w0 = hw & 0xffff;
+      if (h0 < 0x4000) {
+        for (int t = 0; t < a.ntaps; ++t) {
+          const int hh = h0 + a.tdy[t], ww = w0 + a.tdx[t];
+          if (hh >= 1 && hh <= a.Hi && ww >= 1 && ww <= a.Wi) slive[t] = 1;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int n = 0;
+      for (int t = 0; t < a.ntaps; ++t)
+        if (slive[t]) slive[16 + n++] = t;
+      slive[12] = n;
+    }
+    __syncthreads();
+  }
   IG_STAMP(0);          // row tables
 
   // per-thread staging geometry: chunk q = i*THREADS + tid -> LDS row q>>3, lane-linear position q&7
@@ -192,12 +221,13 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
 #pragma unroll
   for (int i = 0; i < Cfg::B_DMA; ++i) b_row_off[i] = (long long)(PP ? b_tile_row(srow + RPI * i) : RPI * i) * a.K * ES;
   const long long b_tap_bytes = (long long)a.N * a.K * ES;
-  const int nk = a.ntaps * a.kc_per_tap;
+  const int nk = (OOB ? slive[12] : a.ntaps) * a.kc_per_tap;
   const uint32_t lds0 = lds_offset_of(smem);
 
   auto stage = [&](int buf, int ks) {
-    const int tap = ks / a.kc_per_tap;
-    const int kc = ks - tap * a.kc_per_tap;
+    const int ti = ks / a.kc_per_tap;
+    const int kc = ks - ti * a.kc_per_tap;
+    const int tap = OOB ? slive[16 + ti] : ti;
     const long long xoff = ((long long)stap[tap] + (long long)kc * BKe) * ES;
     const uint32_t la = lds0 + buf * Cfg::STAGE + wave * 1024;
     if constexpr (OOB) {
