@@ -11,6 +11,8 @@ byte-identical descriptors; the boundary pointers replaced by named slots) — a
 call per launch with prebuilt arguments, the same two streams, the same order. Anything that does not fit (data-parallel
 hooks, SyncBN, the per-kernel profiler, graph capture, eval mode, a recording that differs from its twin) runs the ordinary
 code. `INSAR_TAPE=0` switches tapes off, `INSAR_TAPE=verify` re-records every 16th call and compares it with the tape.
+Recording uses two module-level hooks (`tape.REC`, `_lib._TAPE`): one plan records at a time — two models trained from two
+Python threads of one process should run with INSAR_TAPE=0.
 (The reference launches eagerly, Unet-ChannalAttention.py:338-346; a hipGraph of the step replays slower than eager launches
 on ROCm 7.2 — DESIGN.md — so the tape keeps eager launches and removes the host work around them.)"""
 from __future__ import annotations
@@ -126,8 +128,13 @@ class PlanTape:
 
     # what must not change under a tape (cheap to evaluate per call)
     def _tape_key(self, which: str) -> tuple:
+        from . import engine
         bn = tuple((m.momentum, m.eps) for m in self.bn_modules)
-        return (which, self.sink.active if which == "b" else 0, hash(bn))
+        # module-level switches the launch code reads at call time (tests flip them with monkeypatch): part of the key too
+        flags = (engine.BSTAT_FUSE, engine.BSTAT_C64, engine.COEF_SIMPLE, engine.COEF_FUSE, engine.SPLIT_COEF, engine.POOL_FUSE,
+                 engine.OUTC_FUSE, engine.OUTC_WGRAD_FUSE, engine.PREP_SIDE, engine.WGRAD_LATE, engine.WGRAD_ROWS, engine.FLAT_PP,
+                 engine.FLAT_PERSIST, engine.IGEMM_PP, engine.WGRAD_FILL, engine.WGRAD_FILL_T, engine.WGRAD_GRID_CAP)
+        return (which, self.sink.active if which == "b" else 0, hash(bn), hash(flags))
 
     def _tape_allowed(self, training: bool, extra_ok: bool = True) -> bool:
         from . import engine
