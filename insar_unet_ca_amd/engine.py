@@ -67,6 +67,11 @@ class Ctx:
         # INSAR_SIDE_PRIORITY: HIP stream priority of the side stream (lower number = higher priority; diagnostic)
         self.side = (torch.cuda.Stream(device=device, priority=int(os.environ.get("INSAR_SIDE_PRIORITY", "0")))
                      if device.type == "cuda" and os.environ.get("INSAR_SIDE_STREAM", "1") != "0" else None)
+        # INSAR_SIDE_CU_MASK = <n>[:stride] (diagnostic, measured in round 3): the side stream confined to n compute units
+        # (hipExtStreamCreateWithCUMask; bits 0..n-1 of the mask, or every stride-th bit)
+        mask = os.environ.get("INSAR_SIDE_CU_MASK")
+        if self.side is not None and mask:
+            self.side = _cu_masked_stream(device, mask)
         self._side_busy = False
         self._wgrad_part: Optional[torch.Tensor] = None
         self._wgrad_fold: Optional[torch.Tensor] = None
@@ -156,6 +161,24 @@ class Ctx:
             call("insar_pixel_table", ptr(t), mpad, B, H, W, s, Hb, Wb, tail, _lib.stream_ptr())
             self._tables[key] = t
         return self._tables[key]
+
+
+def _cu_masked_stream(device: torch.device, spec: str):
+    """A HIP stream whose kernels may only use some compute units (hipExtStreamCreateWithCUMask), wrapped for torch."""
+    n, _, stride = spec.partition(":")
+    n, stride = int(n), int(stride or 1)
+    words = [0] * 8                      # 256 CUs
+    for i in range(n):
+        b = (i * stride) % 256 + (i * stride) // 256
+        words[b // 32] |= 1 << (b % 32)
+    hip = C.CDLL("libamdhip64.so")
+    stream = C.c_void_p()
+    arr = (C.c_uint32 * 8)(*words)
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(C.byref(stream), 8, arr)
+    if rc != 0:
+        raise _lib.InsarError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    return torch.cuda.ExternalStream(stream.value, device=device)
 
 
 def _taps_table(self, B: int, Ho: int, Wo: int, s: int, Hb: int, Wb: int, taps) -> torch.Tensor:
