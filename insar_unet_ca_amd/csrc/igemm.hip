@@ -114,7 +114,9 @@ __device__ __forceinline__ void dma_wait_and_barrier() {
 // their DMA burst together and then contending for the matrix pipe (the role alternation of the guide's 8-phase schedule,
 // cdna_hip_programming.md §5; four phases of 16 MFMAs measured the same as two of 32, so the variant with fewer barriers
 // is kept). Same accumulation order as the plain loop: results are bitwise equal (test_pingpong_k_loop_...).
-template <typename T, int BM, int BN, int NSTAGE, bool OOB = false, int PP = 0>
+// BS: BatchNorm-backward sums of the consumer unit in the statistics slab (InsarBstat) — instantiations of their own, so that
+// the plain launches keep the code (and the registers) they had without it.
+template <typename T, int BM, int BN, int NSTAGE, bool OOB = false, int PP = 0, bool BS = false>
 __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(IgemmArgs a) {
   using Cfg = IgemmCfg<T, BM, BN, NSTAGE>;
   constexpr int ES = Cfg::ES, BKe = Cfg::BKe, CH = Chunk<T>::N;
@@ -420,9 +422,9 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
 #pragma unroll
   for (int j = 0; j < CH; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
   // bstat: the consumer unit's y at the output's positions, all of this thread's chunks requested before the first is used
-  uint4 yv[ITER];
-  float bsc[CH], bsh[CH];
-  if (a.by) {
+  uint4 yv[BS ? ITER : 1];
+  float bsc[BS ? CH : 1], bsh[BS ? CH : 1];
+  if constexpr (BS) {
 #pragma unroll
     for (int j = 0; j < CH; ++j) { bsc[j] = a.bscale[ncol + j]; bsh[j] = a.bshift[ncol + j]; }
 #pragma unroll
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
     if (ro >= 0) {
       float f[CH];
       Chunk<T>::unpack(*(const uint4*)(tile + row * Cfg::PITCH + cc * 16), f);
-      if (a.by) {
+      if constexpr (BS) {
         float yy[CH];
         Chunk<T>::unpack(yv[i], yy);
 #pragma unroll
@@ -542,20 +544,24 @@ extern "C" int insar_igemm_num_mtiles(int64_t M, int32_t N) {
   return (int)((M + bm - 1) / bm);
 }
 
-template <typename T, int BM, int BN, int NSTAGE, bool OOB = false, int PP = 0>
-static int launch_igemm(IgemmArgs& a, hipStream_t s) {
+template <typename T, int BM, int BN, int NSTAGE, bool OOB, int PP, bool BS>
+static int launch_igemm_bs(IgemmArgs& a, hipStream_t s) {
   using Cfg = IgemmCfg<T, BM, BN, NSTAGE>;
   static std::atomic<uint64_t> attr_mask{0};     // per-device, see common.h
   {
-    hipError_t e = insar_set_lds_once(attr_mask, (const void*)igemm_kernel<T, BM, BN, NSTAGE, OOB, PP>, Cfg::LDS_BYTES);
+    hipError_t e = insar_set_lds_once(attr_mask, (const void*)igemm_kernel<T, BM, BN, NSTAGE, OOB, PP, BS>, Cfg::LDS_BYTES);
     if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_igemm: hipFuncSetAttribute(%d bytes LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
   }
   a.num_mtiles = (int)((a.M + BM - 1) / BM);
   a.num_ntiles = a.N / BN;
   const int grid = a.num_mtiles * a.num_ntiles;
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, NSTAGE, OOB, PP>), dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, NSTAGE, OOB, PP, BS>), dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, a);
   INSAR_CHECK_LAUNCH("insar_igemm");
   return INSAR_OK;
+}
+template <typename T, int BM, int BN, int NSTAGE, bool OOB = false, int PP = 0>
+static int launch_igemm(IgemmArgs& a, hipStream_t s) {
+  return a.by ? launch_igemm_bs<T, BM, BN, NSTAGE, OOB, PP, true>(a, s) : launch_igemm_bs<T, BM, BN, NSTAGE, OOB, PP, false>(a, s);
 }
 
 extern "C" int insar_igemm(const InsarIgemm* d, void* stream) {
