@@ -65,7 +65,12 @@ struct FlatCfg {
   static constexpr int MAIN = RING > TILE ? RING : TILE;
   static constexpr int ROWINFO = FL_BM * 8;               // rowOut[256] (int64)
   static constexpr int STATB = 8 * BN * 2 * 4;
-  static constexpr int LDS_BYTES = MAIN + ROWINFO + STATB;
+  // bf16, 128 columns: the kernel sits at the 256-register limit and the 16 carried BatchNorm sums of a persistent
+  // work-group were spilled to scratch (17 / 22 spilled registers, reloaded and stored again at every tile); they live in
+  // LDS instead, one 64-byte slot per thread (2 spills left; same-box 7.272 -> 7.256 ms/step)
+  static constexpr bool LDS_CARRY = sizeof(T) == 2 && BN == 128;
+  static constexpr int CARRYB = LDS_CARRY ? FL_THREADS * 2 * (16 / ES) * 4 : 0;
+  static constexpr int LDS_BYTES = MAIN + ROWINFO + STATB + CARRYB;
 };
 
 // Diagnostic build only (-DINSAR_STAMPS, tools/stamp_flat.py): s_memtime stamps of the phases of a tile, summed per
@@ -115,6 +120,11 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
   float cs1[CHc], cs2[CHc];
 #pragma unroll
   for (int j = 0; j < CHc; ++j) { cs1[j] = 0.f; cs2[j] = 0.f; }
+  float4* carry = (float4*)(smem + Cfg::MAIN + Cfg::ROWINFO + Cfg::STATB) + threadIdx.x * (2 * CHc / 4);   // LDS_CARRY only
+  if constexpr (Cfg::LDS_CARRY) {
+#pragma unroll
+    for (int j = 0; j < 2 * CHc / 4; ++j) carry[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 #ifdef INSAR_STAMPS
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // wave-uniform (scalar registers)
   unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
@@ -395,8 +405,19 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
     }
   }
   if (a.stats && a.carry) {
+    if constexpr (Cfg::LDS_CARRY) {
+      // same sums in the same order as the register carry: slot j of the thread += this tile's sum
 #pragma unroll
-    for (int j = 0; j < CH; ++j) { cs1[j] += s1[j]; cs2[j] += s2[j]; }
+      for (int q = 0; q < CH / 4; ++q) {
+        float4 c1v = carry[q], c2v = carry[CH / 4 + q];
+        c1v.x += s1[4 * q]; c1v.y += s1[4 * q + 1]; c1v.z += s1[4 * q + 2]; c1v.w += s1[4 * q + 3];
+        c2v.x += s2[4 * q]; c2v.y += s2[4 * q + 1]; c2v.z += s2[4 * q + 2]; c2v.w += s2[4 * q + 3];
+        carry[q] = c1v; carry[CH / 4 + q] = c2v;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { cs1[j] += s1[j]; cs2[j] += s2[j]; }
+    }
   } else if (a.stats) {
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
@@ -431,6 +452,11 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
   if (a.stats && a.carry) {
     constexpr int CPR = BN * ES / 16;
     constexpr int CH = CHc;
+    if constexpr (Cfg::LDS_CARRY) {
+      const float* cf = (const float*)carry;
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { cs1[j] = cf[j]; cs2[j] = cf[CH + j]; }
+    }
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
 #pragma unroll

@@ -358,45 +358,50 @@ extern "C" int insar_colsum_partial(const float* part, float* out, int64_t rows,
 // BatchNorm finalize (Unet-ChannalAttention.py:82,85; nn.BatchNorm2d training/eval semantics)
 // sums[0][c] = sum y_raw, sums[1][c] = sum y_raw^2 over `count` pixels (y_raw = conv w/o bias).
 // ---------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(InsarBnFinalize d) {
-  // 64 channels per block, 8 row lanes per channel (threadIdx = lane*64 + channel)
-  __shared__ double fold[2][8][64];
+#define BNF_LANES 16
+__global__ void __launch_bounds__(64 * BNF_LANES) bn_finalize_kernel(InsarBnFinalize d) {
+  // 64 channels per block, BNF_LANES row lanes per channel (threadIdx = lane*64 + channel)
+  __shared__ double fold[2][BNF_LANES][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   if (c == 0 && rl == 0 && d.training && d.num_batches_tracked) *d.num_batches_tracked += 1;
+  // the channel's parameters: requested before the fold, used after it
+  const bool fin = rl == 0 && c < d.C;
+  const float cb = (fin && d.conv_bias) ? d.conv_bias[c] : 0.f;
+  const float gamma_c = fin ? d.gamma[c] : 0.f, beta_c = fin ? d.beta[c] : 0.f;
+  const float rm_c = (fin && d.running_mean) ? d.running_mean[c] : 0.f, rv_c = (fin && d.running_var) ? d.running_var[c] : 0.f;
   if (d.training) {
     double s1 = 0.0, s2 = 0.0;
     if (c < d.C) {
-      // fold the remaining partial rows [rows][2][C]: four independent chains so that a thread's loads overlap
-      // (this launch sits between a conv and its BN/ReLU pass on the forward chain: it is pure latency)
-      double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+      // fold the remaining partial rows [rows][2][C]: eight rows of a lane requested before the first is added (this
+      // launch sits between a conv and its BN/ReLU pass on the forward chain: it is pure latency — rows / 128 dependent
+      // round trips with 16 lanes x 8 in flight, where 8 lanes x 4 took rows / 32)
       int64_t r = rl;
-      for (; r + 24 < d.rows; r += 32) {
+      for (; r + 7 * BNF_LANES < d.rows; r += 8 * BNF_LANES) {
+        float v1[8], v2[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          a1[u] += (double)d.part[((r + 8 * u) * 2 + 0) * d.C + c];
-          a2[u] += (double)d.part[((r + 8 * u) * 2 + 1) * d.C + c];
+        for (int u = 0; u < 8; ++u) {
+          v1[u] = d.part[((r + BNF_LANES * u) * 2 + 0) * d.C + c];
+          v2[u] = d.part[((r + BNF_LANES * u) * 2 + 1) * d.C + c];
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s1 += (double)v1[u]; s2 += (double)v2[u]; }
       }
-      for (; r < d.rows; r += 8) {
-        a1[0] += (double)d.part[(r * 2 + 0) * d.C + c];
-        a2[0] += (double)d.part[(r * 2 + 1) * d.C + c];
+      for (; r < d.rows; r += BNF_LANES) {
+        s1 += (double)d.part[(r * 2 + 0) * d.C + c];
+        s2 += (double)d.part[(r * 2 + 1) * d.C + c];
       }
-      s1 = (a1[0] + a1[1]) + (a1[2] + a1[3]);
-      s2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
     }
     fold[0][rl][cl] = s1; fold[1][rl][cl] = s2;
     __syncthreads();
   }
-  if (rl != 0 || c >= d.C) return;
-  const float cb = d.conv_bias ? d.conv_bias[c] : 0.f;
+  if (!fin) return;
   float mean_raw, invstd;
   if (d.training) {
     const double n = (double)d.count;
-    const double s1 = ((fold[0][0][cl] + fold[0][1][cl]) + (fold[0][2][cl] + fold[0][3][cl])) +
-                      ((fold[0][4][cl] + fold[0][5][cl]) + (fold[0][6][cl] + fold[0][7][cl]));
-    const double s2 = ((fold[1][0][cl] + fold[1][1][cl]) + (fold[1][2][cl] + fold[1][3][cl])) +
-                      ((fold[1][4][cl] + fold[1][5][cl]) + (fold[1][6][cl] + fold[1][7][cl]));
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < BNF_LANES; ++k) { s1 += fold[0][k][cl]; s2 += fold[1][k][cl]; }
     const double m = s1 / n;
     double var = s2 / n - m * m;
     if (var < 0) var = 0;
@@ -404,17 +409,17 @@ __global__ void bn_finalize_kernel(InsarBnFinalize d) {
     invstd = (float)(1.0 / sqrt(var + (double)d.eps));
     if (d.running_mean) {
       const double unbiased = n > 1 ? var * n / (n - 1) : var;
-      d.running_mean[c] = (1.f - d.momentum) * d.running_mean[c] + d.momentum * (float)(m + cb);
-      d.running_var[c] = (1.f - d.momentum) * d.running_var[c] + d.momentum * (float)unbiased;
+      d.running_mean[c] = (1.f - d.momentum) * rm_c + d.momentum * (float)(m + cb);
+      d.running_var[c] = (1.f - d.momentum) * rv_c + d.momentum * (float)unbiased;
     }
   } else {
     // eval: y = (y_raw + cb - running_mean) / sqrt(running_var + eps): "mean of y_raw" = rm - cb
-    mean_raw = d.running_mean[c] - cb;
-    invstd = 1.f / sqrtf(d.running_var[c] + d.eps);
+    mean_raw = rm_c - cb;
+    invstd = 1.f / sqrtf(rv_c + d.eps);
   }
-  const float sc = d.gamma[c] * invstd;
+  const float sc = gamma_c * invstd;
   d.scale[c] = sc;
-  d.shift[c] = d.beta[c] - mean_raw * sc;
+  d.shift[c] = beta_c - mean_raw * sc;
   d.mean[c] = mean_raw;
   d.invstd[c] = invstd;
 }
@@ -425,7 +430,7 @@ extern "C" int insar_bn_finalize(const InsarBnFinalize* d, void* stream) {
   if (d->training && (!d->part || d->count < 1 || d->rows < 1 || d->rows > 4096))
     INSAR_FAIL(INSAR_E_ARG, "insar_bn_finalize: training needs 1..4096 rows of partial sums");
   if (!d->training && (!d->running_mean || !d->running_var)) INSAR_FAIL(INSAR_E_ARG, "insar_bn_finalize: eval needs running stats");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->C + 63) / 64), dim3(512), 0, (hipStream_t)stream, *d);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->C + 63) / 64), dim3(64 * BNF_LANES), 0, (hipStream_t)stream, *d);
   INSAR_CHECK_LAUNCH("insar_bn_finalize");
   return INSAR_OK;
 }
@@ -1246,6 +1251,10 @@ __global__ void __launch_bounds__(COEF_THREADS) bnse_bwd_stage1(BnSeBwdArgs a) {
 }
 
 // element `tid` of stage 2 (a channel and / or an SE weight)
+// (The three sums over the images are dependent load + fma chains, 48 L2 round trips = 12 us per launch. Requesting the
+// sixteen images' operands together brings the launch to 6 us and the STEP from 7.34 to 7.39 ms, same-box, five
+// interleaved rounds: on the input-gradient chain a latency-bound launch is a window in which the side stream's weight
+// gradient has the chip to itself, and closing it moves that work beside the next MFMA-bound launch of the chain. Kept slow.)
 template <bool COH>
 __device__ __forceinline__ void bnse_stage2_elem(const BnSeBwdArgs& a, int64_t tid) {
   const InsarBnSeBwd& d = a.d;
@@ -1378,32 +1387,39 @@ extern "C" int insar_bnse_bwd_coef_fused(const InsarBnSeBwd* d, const float* red
 // whose work-groups own 64 channels each and fold ALL rows (B * rows of them, any partition of the pixels):
 //   P = sum_rows red[.][0][c], Q = sum_rows red[.][1][c];  dbeta = P;  dgamma = invstd * (Q - mean * P);
 //   k1 = dbeta / N, k2 = dgamma / N (training; 0 in eval mode);  conv-bias gradient 0 (training) / scale * dbeta (eval).
-// 256 threads = 64 channels x 4 row groups (coalesced 256-byte row segments), folded through LDS in a fixed order:
-// deterministic, no hand-off between work-groups (the two-stage kernels above run 16 work-groups and then one).
-__global__ void __launch_bounds__(256) bn_bwd_coef_kernel(const float* __restrict__ red, int64_t rows, int C,
+// 1024 threads = 64 channels x 16 row groups (coalesced 256-byte row segments), eight rows of a group in flight, folded
+// through LDS in a fixed order: deterministic, no hand-off between work-groups (the two-stage kernels above run 16
+// work-groups and then one). The launch is pure latency on the input-gradient chain (C / 64 work-groups reading a slab of up
+// to 1024 rows): with 4 row groups and 4 rows in flight it took rows / 16 dependent L2 round trips, now rows / 128.
+#define BNC_GROUPS 16
+__global__ void __launch_bounds__(64 * BNC_GROUPS) bn_bwd_coef_kernel(const float* __restrict__ red, int64_t rows, int C,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ scale, float inv_count, int training,
                                                           int accumulate, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                           float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ dconv_bias) {
-  __shared__ float sp[4][64], sq[4][64];
+  __shared__ float sp[BNC_GROUPS][64], sq[BNC_GROUPS][64];
   const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   float p = 0.f, q = 0.f;
   if (c < C) {
     int64_t r = g;
-    for (; r + 12 < rows; r += 16) {            // four rows of this group in flight
+    const int64_t st = (int64_t)BNC_GROUPS * 2 * C;            // floats between two rows of this group
+    for (; r + 7 * BNC_GROUPS < rows; r += 8 * BNC_GROUPS) {
       const float* b = red + r * 2 * C + c;
-      const float p0 = b[0], q0 = b[C], p1 = b[8 * (int64_t)C], q1 = b[9 * (int64_t)C];
-      const float p2 = b[16 * (int64_t)C], q2 = b[17 * (int64_t)C], p3 = b[24 * (int64_t)C], q3 = b[25 * (int64_t)C];
-      p += p0; q += q0; p += p1; q += q1; p += p2; q += q2; p += p3; q += q3;
+      float pv[8], qv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { pv[u] = b[u * st]; qv[u] = b[u * st + C]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { p += pv[u]; q += qv[u]; }
     }
-    for (; r < rows; r += 4) { p += red[r * 2 * C + c]; q += red[(r * 2 + 1) * C + c]; }
+    for (; r < rows; r += BNC_GROUPS) { p += red[r * 2 * C + c]; q += red[(r * 2 + 1) * C + c]; }
   }
   sp[g][cl] = p; sq[g][cl] = q;
   __syncthreads();
   if (g == 0 && c < C) {
-    const float P = (sp[0][cl] + sp[1][cl]) + (sp[2][cl] + sp[3][cl]);
-    const float Q = (sq[0][cl] + sq[1][cl]) + (sq[2][cl] + sq[3][cl]);
+    float P = 0.f, Q = 0.f;
+#pragma unroll
+    for (int k = 0; k < BNC_GROUPS; ++k) { P += sp[k][cl]; Q += sq[k][cl]; }
     const float dg = invstd[c] * (Q - mean[c] * P);
     k1[c] = training ? P * inv_count : 0.f;
     k2[c] = training ? dg * inv_count : 0.f;
@@ -1422,7 +1438,7 @@ extern "C" int insar_bn_bwd_coef(const InsarBnSeBwd* d, const float* red, int64_
   if (d->use_se) INSAR_FAIL(INSAR_E_ARG, "insar_bn_bwd_coef: units with an SE gate need insar_bnse_bwd_coef (per-image stage)");
   if (d->C < 1 || d->B < 1 || rows_total < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_bn_bwd_coef: bad shape");
   const float inv_count = 1.f / ((float)d->B * (float)d->H * (float)d->W);
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((d->C + 63) / 64), dim3(256), 0, (hipStream_t)stream, red, rows_total, d->C, d->mean,
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((d->C + 63) / 64), dim3(64 * BNC_GROUPS), 0, (hipStream_t)stream, red, rows_total, d->C, d->mean,
                      d->invstd, scale, inv_count, training, d->accumulate, d->dgamma, d->dbeta, d->k1, d->k2, dconv_bias);
   INSAR_CHECK_LAUNCH("insar_bn_bwd_coef");
   return INSAR_OK;
@@ -1439,10 +1455,15 @@ extern "C" int insar_bnse_bwd_coef_stage(const InsarBnSeBwd* d, const float* red
   return launch_bnse_coef("insar_bnse_bwd_coef_stage", d, red, rows, scale, shift, ws, dconv_bias, training, stage, stream);
 }
 
-// dy = scale * ( (dout*gate + coefB) * mask - k1 - xhat*k2 ),  xhat = (y - mean)*invstd
+// dy = scale * ( (dout*gate + coefB) * mask - k1 - xhat*k2 ),  xhat = (y - mean)*invstd, evaluated with the per-channel
+// constants folded:  dy = (mask ? dout*p + q : 0) + (a0 + a1*y),  p = scale*gate[n], q = scale*coefB[n],
+// a1 = -scale*invstd*k2, a0 = -scale*k1 - a1*mean  (six constants per channel instead of eight, five VALU operations per
+// element instead of nine). The plain instantiation is bounded by the 256 threads it is launched with, not by 1024: at
+// 128 registers it spilled eight of them and reloaded them (with a full vmcnt wait) at every image row; 135 registers,
+// three waves per SIMD, no spill: 88 -> 76 us at the 256^2 level, the step 7.38 -> 7.31 ms (profiles/r03_pass_bench.txt).
 #define BWD_APPLY_MAXC 1024
 template <typename T, int VK = 0, bool VP = false>       // VK, VP as in row_reduce_kernel
-__global__ void __launch_bounds__((VK || VP) ? 512 : 1024) bnrelu_bwd_apply_kernel(ActView g, ActView y, const float* __restrict__ scale,
+__global__ void __launch_bounds__((VK || VP) ? 512 : 256) bnrelu_bwd_apply_kernel(ActView g, ActView y, const float* __restrict__ scale,
                                         const float* __restrict__ shift, const float* __restrict__ mean,
                                         const float* __restrict__ invstd, const float* __restrict__ gate,
                                         const float* __restrict__ coefB, const float* k1,
@@ -1467,15 +1488,42 @@ __global__ void __launch_bounds__((VK || VP) ? 512 : 1024) bnrelu_bwd_apply_kern
     __syncthreads();
     k1 = sk; k2 = sk + BWD_APPLY_MAXC;
   }
-  float sc[CH], sh[CH], mu[CH], is[CH], ga[CH], cb[CH], c1[CH], c2[CH];
-  if (inv) {
-    const int cc = threadIdx.x % cpp, wstep = blockDim.x / cpp;
+  float sc[CH], sh[CH], fp[CH], fq[CH], a0[CH], a1[CH];
+  auto load_channel_consts = [&](int c0) {
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      const int c = cc * CH + j;
-      sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c]; c1[j] = k1[c]; c2[j] = k2[c];
-      ga[j] = 1.f; cb[j] = 0.f;
+      const int c = c0 + j;
+      sc[j] = scale[c]; sh[j] = shift[c];
+      a1[j] = -sc[j] * invstd[c] * k2[c];
+      a0[j] = -sc[j] * k1[c] - a1[j] * mean[c];
+      fp[j] = sc[j]; fq[j] = 0.f;
     }
+  };
+  // the image's gate / coefB chunk: 16-byte loads issued together behind ONE test of each pointer (written per element,
+  // `if (gate) fp[j] = ...` became sixteen dependent load + full-wait pairs at the head of every image row)
+  auto load_image_consts = [&](int n, int c0) {
+    float4 gv[CH / 4], bv[CH / 4];
+    const int64_t off = (int64_t)n * y.c_len + c0;
+    if (gate) {
+#pragma unroll
+      for (int q = 0; q < CH / 4; ++q) gv[q] = *(const float4*)(gate + off + 4 * q);
+    }
+    if (coefB) {
+#pragma unroll
+      for (int q = 0; q < CH / 4; ++q) bv[q] = *(const float4*)(coefB + off + 4 * q);
+    }
+    if (gate) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) fp[j] = sc[j] * ((const float*)gv)[j];
+    }
+    if (coefB) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) fq[j] = sc[j] * ((const float*)bv)[j];
+    }
+  };
+  if (inv) {
+    const int cc = threadIdx.x % cpp, wstep = blockDim.x / cpp;
+    load_channel_consts(cc * CH);
     constexpr bool virt = VK > 0;                     // dout recomputed from dlogits (see OutcGrad): own instantiation
     constexpr int KM = virt ? VK : 1;
     float wk[KM][CH];
@@ -1490,11 +1538,7 @@ __global__ void __launch_bounds__((VK || VP) ? 512 : 1024) bnrelu_bwd_apply_kern
     for (int r = blockIdx.x; r < rows; r += gridDim.x) {
       const int n = r / y.H, h = r - n * y.H;
       if (n != n_loaded) {
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-          if (gate) ga[j] = gate[(int64_t)n * y.c_len + cc * CH + j];
-          if (coefB) cb[j] = coefB[(int64_t)n * y.c_len + cc * CH + j];
-        }
+        load_image_consts(n, cc * CH);
         n_loaded = n;
       }
       for (int w0 = threadIdx.x / cpp; w0 < y.W; w0 += PW_UNROLL * wstep) {
@@ -1528,9 +1572,8 @@ __global__ void __launch_bounds__((VK || VP) ? 512 : 1024) bnrelu_bwd_apply_kern
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
               const bool on = !relu || fmaf(f[j], sc[j], sh[j]) > 0.f;
-              const float ge = on ? fmaf(gg[j], ga[j], cb[j]) : 0.f;
-              const float xh = (f[j] - mu[j]) * is[j];
-              o[j] = sc[j] * (ge - c1[j] - xh * c2[j]);
+              const float ge = on ? fmaf(gg[j], fp[j], fq[j]) : 0.f;
+              o[j] = ge + fmaf(f[j], a1[j], a0[j]);
             }
             *chunk_ptr_w<T>(dy, n, h, w0 + u * wstep, cc) = Chunk<T>::pack(o);
           }
@@ -1538,26 +1581,21 @@ __global__ void __launch_bounds__((VK || VP) ? 512 : 1024) bnrelu_bwd_apply_kern
     }
     return;
   }
+  // generic (slow) path: any channel count
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const int n = r / y.H, h = r - n * y.H;
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
       const int w = e / cpp, cc = e - w * cpp;
-#pragma unroll
-      for (int j = 0; j < CH; ++j) {
-        const int c = cc * CH + j;
-        sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c]; c1[j] = k1[c]; c2[j] = k2[c];
-        ga[j] = gate ? gate[(int64_t)n * y.c_len + c] : 1.f;
-        cb[j] = coefB ? coefB[(int64_t)n * y.c_len + c] : 0.f;
-      }
+      load_channel_consts(cc * CH);
+      load_image_consts(n, cc * CH);
       float f[CH], gg[CH], o[CH];
       Chunk<T>::unpack(*chunk_ptr<T>(y, n, h, w, cc), f);
       Chunk<T>::unpack(*chunk_ptr<T>(g, n, h, w, cc), gg);
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
         const bool on = !relu || fmaf(f[j], sc[j], sh[j]) > 0.f;
-        const float ge = on ? fmaf(gg[j], ga[j], cb[j]) : 0.f;
-        const float xh = (f[j] - mu[j]) * is[j];
-        o[j] = sc[j] * (ge - c1[j] - xh * c2[j]);
+        const float ge = on ? fmaf(gg[j], fp[j], fq[j]) : 0.f;
+        o[j] = ge + fmaf(f[j], a1[j], a0[j]);
       }
       *chunk_ptr_w<T>(dy, n, h, w, cc) = Chunk<T>::pack(o);
     }
@@ -1578,6 +1616,7 @@ static int launch_bwd_apply(const char* who, const InsarAct* dout, const InsarAc
   if ((rc = check_same_grid(y, dy, who))) return rc;
   if (!scale || !shift || !mean || !invstd) INSAR_FAIL(INSAR_E_ARG, "%s: null pointer", who);
   if (!tb && (!k1 || !k2)) INSAR_FAIL(INSAR_E_ARG, "%s: null k1/k2", who);
+  if ((gate && !insar_aligned16(gate)) || (coefB && !insar_aligned16(coefB))) INSAR_FAIL(INSAR_E_ALIGN, "%s: gate / coefB not 16-byte aligned", who);
   if (tb && (!tg || y->c_len > BWD_APPLY_MAXC))
     INSAR_FAIL(INSAR_E_SHAPE, "%s: partial sums need tg and C <= %d", who, BWD_APPLY_MAXC);
   int grid = insar_grid_cap((int64_t)y->B * y->H);

@@ -226,7 +226,7 @@ class ConvUnit:
             raise _lib.InsarError(f"{name}: output slice does not match the convolution")
         self.stat_rows = call("insar_igemm_num_mtiles", self.M, self.cout)
         self.stats = ctx.f32(self.stat_rows, 2, self.cout)
-        self.stat_rps = 0 if self.stat_rows <= 256 else max(64, -(-self.stat_rows // 64))
+        self.stat_rps = 0 if self.stat_rows <= engine.STAT_PREFOLD_ROWS else max(64, -(-self.stat_rows // 64))
         self.fold_rows = self.stat_rows if not self.stat_rps else -(-self.stat_rows // self.stat_rps)
         self.sums = ctx.f32(self.fold_rows, 2, self.cout) if self.stat_rps else self.stats
         self.scale, self.shift, self.mean, self.invstd = (ctx.f32(self.cout) for _ in range(4))

@@ -337,6 +337,10 @@ WGRAD_ROWS = os.environ.get("INSAR_WGRAD_ROWS", "1") != "0"      # diagnostic: 0
 FLAT_PP = int(os.environ.get("INSAR_FLAT_PP", "1"))               # flat 3x3 kernel: ping-pong tap steps (0 = plain loop; bitwise equal)
 FLAT_PERSIST = int(os.environ.get("INSAR_FLAT_PERSIST", "2"))     # flat 3x3 kernel: one work-group per CU walking its tiles (bitwise equal): 1 = forward launches, 2 = all (default since round 3: with the BatchNorm-backward sums carried over a work-group's tiles the input-gradient launches gain too, same-box 7.55 -> 7.49 ms/step), 0 = off
 IGEMM_PP = int(os.environ.get("INSAR_IGEMM_PP", "1"))            # 256 x 256 tiles: ping-pong K loop (0 = the plain two-slab loop; bitwise equal)
+# BatchNorm statistics slabs with more rows than this get a pre-fold launch (insar_colsum_partial) before insar_bn_finalize;
+# up to it the finalize launch folds the slab itself (16 row lanes x 8 rows in flight: 1024 rows are 8 round trips, cheaper
+# than the extra launch on the forward chain)
+STAT_PREFOLD_ROWS = int(os.environ.get("INSAR_STAT_PREFOLD_ROWS", "1024"))
 BSTAT_FUSE = os.environ.get("INSAR_BSTAT_FUSE", "1") != "0"      # diagnostic: 0 = BatchNorm-backward sums always in a pass of their own
 BSTAT_C64 = os.environ.get("INSAR_BSTAT_C64", "1") != "0"       # the 64 -> 64 kernel's variant of it. Alone it costs more than it saves (8-byte y loads from the accumulator layout: 89 -> 140 us per launch against the 43 us reduce pass it replaces), in the step it wins (same-box A/B 7.70 -> 7.61 ms: one launch less on the dgrad chain beside the weight-gradient stream)
 WGRAD_LATE = os.environ.get("INSAR_WGRAD_ORDER", "before") == "after"      # diagnostic / tuning switch, see ConvBN.backward
@@ -581,7 +585,7 @@ class ConvBN:
             self.stat_rows = call("insar_igemm_num_mtiles", self.M, self.cout)
         self.stats = ctx.f32(self.stat_rows, 2, self.cout)
         # BN partial sums: slabs with many rows are folded to <= 64 rows first, bn_finalize folds the rest
-        self.stat_rps = 0 if self.stat_rows <= 256 else max(64, -(-self.stat_rows // 64))
+        self.stat_rps = 0 if self.stat_rows <= STAT_PREFOLD_ROWS else max(64, -(-self.stat_rows // 64))
         self.fold_rows = self.stat_rows if not self.stat_rps else -(-self.stat_rows // self.stat_rps)
         self.sums = ctx.f32(self.fold_rows, 2, self.cout) if self.stat_rps else self.stats
         self.scale, self.shift = ctx.f32(self.cout), ctx.f32(self.cout)

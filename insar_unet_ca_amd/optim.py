@@ -4,13 +4,16 @@ torch.optim.Adam's own format, so optimizer.state_dict() interchanges with the r
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
 from . import _lib
 from ._lib import call, ptr
 
-CHUNK = 65536
+# elements per work-group of the Adam launch (256 threads): small enough for every CU to hold several work-groups for the
+# whole launch. 31 M parameters in one buffer, stand-alone (tools/pass_bench.py): 64 Ki 177 us, 16 Ki 175, 8 Ki 166, 4 Ki 165.
+CHUNK = int(os.environ.get("INSAR_ADAM_CHUNK", "8192"))
 
 
 class Adam(torch.optim.Adam):
