@@ -259,6 +259,8 @@ static int launch_wgrad(WgradArgs& a, hipStream_t s) {
 // except that 256 is used only when BOTH dimensions allow it: 8 waves, 128 KB of LDS, half the DMA pieces per MFMA).
 extern "C" int insar_wgrad_tile(int32_t C, int32_t dtype) {
   if (dtype != INSAR_BF16) return (C % 128) == 0 ? 128 : 64;      // fp32: 128 x 128 (8 waves) only when BOTH allow it
+  const int cap = insar_knob(KNOB_WGRAD_TILE_MAX);
+  if (cap > 0 && cap < 256) return (C % 128) == 0 ? 128 : 64;
   return (C % 256) == 0 ? 256 : ((C % 128) == 0 ? 128 : 64);
 }
 

@@ -943,12 +943,17 @@ def test_dice_against_oracle_definition(dev):
     assert max_rel(a.grad, b.grad) <= 1e-4
 
 
+@pytest.mark.parametrize("shape", [(3, 2, 32, 48), (2, 3, 16, 20), (2, 4, 8, 12), (2, 2, 15, 17), (2, 5, 16, 16)],
+                         ids=["k2_vec4", "k3_vec4", "k4_vec4", "k2_odd_hw", "k5_generic"])
 @pytest.mark.parametrize("wce,wd", [(1.0, 1.0), (0.3, 0.7)])
-def test_fused_dice_ce_against_oracle(dev, wce, wd):
-    """DiceCELoss (one statistics pass + one gradient pass) == ce_weight*CE + dice_weight*Dice of the oracle."""
+def test_fused_dice_ce_against_oracle(dev, wce, wd, shape):
+    """DiceCELoss (one statistics pass + one gradient pass) == ce_weight*CE + dice_weight*Dice of the oracle: the
+    four-pixels-per-thread kernels (K <= 4 classes, H*W a multiple of 4) and the per-pixel ones (any K, any size)."""
     import insar_unet_ca_amd as iu
-    lg = cf.make_input((3, 2, 32, 48), 0.9) * 3.0
-    tgt = cf.make_target((3, 32, 48), ignore_every=5)
+    lg = cf.make_input(shape, 0.9) * 3.0
+    base = cf.make_target((shape[0],) + shape[2:], ignore_every=5)              # {0, 1} and 255 at the ignored pixels
+    n, yy, xx = torch.meshgrid(*(torch.arange(d) for d in base.shape), indexing="ij")
+    tgt = torch.where(base == 255, base, (xx * 3 + yy * 5 + n * 7) % shape[1])    # every class of K occurs
     a = lg.clone().to(dev).requires_grad_(True)
     crit = iu.DiceCELoss(ignore_index=255, ce_weight=wce, dice_weight=wd)
     d = crit(a, tgt.to(dev))

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Same-box A/B of environment settings: `rounds` interleaved bench runs of the default and of every "NAME=VALUE[,NAME=VALUE]"
+# setting named. usage: ab_env.sh <rounds> "<bench args>" <env1> [env2 ...]     e.g. ab_env.sh 3 "--model deeplab" INSAR_TUNE=wgrad_tile_max=128
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+N=$1; ARGS=$2; shift 2
+pick='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], d["ms_per_step"], d["value"])'
+for i in $(seq $N); do
+  timeout -k 10 200 python3 $R/bench.py $ARGS --steps 30 --warmup 8 --no-cpu-baseline --no-kernel-timing --no-other-configs 2>/dev/null | python3 -c "$pick" default || exit 1
+  for E in "$@"; do
+    env ${E//;/ } timeout -k 10 200 python3 $R/bench.py $ARGS --steps 30 --warmup 8 --no-cpu-baseline --no-kernel-timing --no-other-configs 2>/dev/null | python3 -c "$pick" "$E" || exit 1
+  done
+done

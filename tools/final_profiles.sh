@@ -59,3 +59,4 @@ timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2
 echo "== config 4"; timeout -k 10 300 python3 "$R/bench.py" --dtype f32 --size 512 --batch 8 --loss ce --no-cpu-baseline > "$OUT/bench_cfg4.json" 2> "$OUT/bench_cfg4.err"; cut -c1-200 "$OUT/bench_cfg4.json"
 echo "== config 5"; timeout -k 10 300 python3 "$R/bench.py" --model deeplab --no-cpu-baseline > "$OUT/bench_cfg5.json" 2> "$OUT/bench_cfg5.err"; cut -c1-200 "$OUT/bench_cfg5.json"
 echo done
+echo "== stand-alone pass timings"; timeout -k 10 300 python3 "$R/tools/pass_bench.py" 2>/dev/null | tee "$OUT/pass_bench.txt"
