@@ -1046,27 +1046,50 @@ extern "C" int insar_bnrelu_bwd_reduce_outc(const float* dlogits, const float* w
 // columns across lanes (coalesced), row lanes when cols < blockDim. `scratch` needs blockDim floats.
 #define COEF_THREADS 1024   // per-image coefficient kernels (se_excite, bnse_bwd_stage1): 16 waves
 
-__device__ __forceinline__ float strided_sum4(const float* __restrict__ p, int first, int rows, int step, int64_t ld) {
-  // four independent partial sums so that the loads of one thread overlap (fixed order => deterministic)
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+__device__ __forceinline__ float strided_sum16(const float* __restrict__ p, int first, int rows, int step, int64_t ld) {
+  // sixteen independent partial sums so that the loads of one thread overlap: these folds sit at the head of latency-bound
+  // launches (se_excite on the forward chain), where every dependent round trip is ~0.5 us (fixed order => deterministic)
+  float a[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) a[u] = 0.f;
   int r = first;
-  for (; r + 3 * step < rows; r += 4 * step) {
-    a0 += p[(int64_t)r * ld]; a1 += p[(int64_t)(r + step) * ld];
-    a2 += p[(int64_t)(r + 2 * step) * ld]; a3 += p[(int64_t)(r + 3 * step) * ld];
+  for (; r + 15 * step < rows; r += 16 * step) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = p[(int64_t)(r + u * step) * ld];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a[u] += v[u];
   }
-  for (; r < rows; r += step) a0 += p[(int64_t)r * ld];
-  return (a0 + a1) + (a2 + a3);
+  if (r + 7 * step < rows) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(r + u * step) * ld];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += v[u];
+    r += 8 * step;
+  }
+  if (r + 3 * step < rows) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = p[(int64_t)(r + u * step) * ld];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] += v[u];
+    r += 4 * step;
+  }
+  for (; r < rows; r += step) a[0] += p[(int64_t)r * ld];
+  return (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) +
+         (((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15])));
 }
 
 __device__ __forceinline__ void block_colsum(const float* __restrict__ slab, int rows, int cols, float* out, float* scratch) {
   const int nt = blockDim.x;
   if (cols >= nt) {
-    for (int c = threadIdx.x; c < cols; c += nt) out[c] = strided_sum4(slab + c, 0, rows, 1, cols);
+    for (int c = threadIdx.x; c < cols; c += nt) out[c] = strided_sum16(slab + c, 0, rows, 1, cols);
     __syncthreads();
   } else {
     const int lanes = nt / cols;                       // row lanes; threads beyond lanes*cols idle
     const int c = threadIdx.x % cols, rl = threadIdx.x / cols;
-    scratch[threadIdx.x] = rl < lanes ? strided_sum4(slab + c, rl, rows, lanes, cols) : 0.f;
+    scratch[threadIdx.x] = rl < lanes ? strided_sum16(slab + c, rl, rows, lanes, cols) : 0.f;
     __syncthreads();
     if (threadIdx.x < cols) {
       float t = 0.f;
@@ -1093,6 +1116,31 @@ __global__ void __launch_bounds__(COEF_THREADS) se_excite_kernel(InsarSeFwd d) {
   const int n = blockIdx.x;
   const bool writer = blockIdx.y == 0;
   const float inv_hw = 1.f / ((float)d.H * (float)d.W);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int per = (d.C + gridDim.y - 1) / gridDim.y;
+  const int cbeg = blockIdx.y * per, cend = min(d.C, cbeg + per);
+  // Both Linears' weights of this wave are requested BEFORE the squeeze rows are folded (they depend on nothing): the
+  // launch is a chain of dependent round trips on the forward path — fold, first Linear, second Linear — and this takes
+  // the two weight fetches out of it. Shapes of the U-Net (C <= 1024, C / r <= 64, 16 waves); others take the plain loops.
+  constexpr int PJ = 4, PC = 16, PU = 8;
+  const bool pre = d.C <= 64 * PC && d.Cr <= PJ * 16 && nw == 16 && per <= PU * 16 && d.Cr <= 64;
+  float w1v[PJ][PC], w2v[PU];
+  if (pre) {
+#pragma unroll
+    for (int q = 0; q < PJ; ++q) {
+      const int j = wave + q * 16;
+#pragma unroll
+      for (int e = 0; e < PC; ++e) {
+        const int c = lane + 64 * e;
+        w1v[q][e] = (j < d.Cr && c < d.C) ? d.w1[(int64_t)j * d.C + c] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const int c = cbeg + wave + u * 16;
+      w2v[u] = (c < cend && lane < d.Cr) ? d.w2[(int64_t)c * d.Cr + lane] : 0.f;
+    }
+  }
   // fold this image's squeeze rows: part[(n*rows + r)][2][C]
   block_colsum(d.part + (int64_t)n * d.rows * 2 * d.C, d.rows, 2 * d.C, pool, scratch);
   for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
@@ -1107,7 +1155,36 @@ __global__ void __launch_bounds__(COEF_THREADS) se_excite_kernel(InsarSeFwd d) {
     }
   }
   __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  if (pre) {
+    // same products in the same order as the plain loops below (c = lane, lane + 64, ...; j = lane)
+#pragma unroll
+    for (int q = 0; q < PJ; ++q) {
+      const int j = wave + q * 16;
+      if (j < d.Cr) {                                   // wave-uniform
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < PC; ++e) {
+          const int c = lane + 64 * e;
+          if (c < d.C) acc = fmaf(w1v[q][e], sq[c], acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+          const float hv = fmaxf(acc, 0.f);
+          hid[j] = hv;
+          if (writer) d.hid[(int64_t)n * d.Cr + j] = hv;
+        }
+      }
+    }
+    __syncthreads();
+    const float hl = lane < d.Cr ? hid[lane] : 0.f;
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const int c = cbeg + wave + u * 16;
+      const float t = wave_sum(lane < d.Cr ? fmaf(w2v[u], hl, 0.f) : 0.f);
+      if (lane == 0 && c < cend) d.gate[(int64_t)n * d.C + c] = 1.f / (1.f + __expf(-t));
+    }
+    return;
+  }
   for (int j = wave; j < d.Cr; j += nw) {
     float acc = 0.f;
 #pragma unroll 8
@@ -1122,8 +1199,6 @@ __global__ void __launch_bounds__(COEF_THREADS) se_excite_kernel(InsarSeFwd d) {
   __syncthreads();
   // gate[c] = sigmoid(sum_j w2[c][j] * hid[j]): one wave per row of w2, lanes over j (coalesced)
   // (8 rows per trip so that their loads are in flight together); this work-group's slice of the rows
-  const int per = (d.C + gridDim.y - 1) / gridDim.y;
-  const int cbeg = blockIdx.y * per, cend = min(d.C, cbeg + per);
   for (int c0 = cbeg + wave; c0 < cend; c0 += 8 * nw) {
     float acc[8];
 #pragma unroll

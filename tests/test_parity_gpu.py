@@ -753,8 +753,9 @@ def test_unet_fp32_gradients_given_equal_relu_decisions(dev, fixture, shape):
             assert e <= (0.35 if k.endswith("fc.0.weight") else 0.1), f"bf16: gradient rel-L2 {e:.3e} at {k}"
         return
     smooth = fixture == "closed-form"      # degenerate (near-constant) channels: invstd up to 316 amplifies the noise
-    # closed-form 256x256: measured 425 ReLU decisions (largest |z| 1.1e-3) and 10 pool decisions differ: gates at 2x
-    assert flips <= (850 if smooth else 40) and worst_z < (2.2e-3 if smooth else 1e-4) and pool_flips <= 40, \
+    # closed-form 256x256: measured 425-428 ReLU decisions and 9-10 pool decisions differ: gates at 2x. The largest |z|
+    # among them is one position's noise: 1.1e-3 and 2.3e-3 under two summation orders of the SE squeeze fold: gate 4e-3
+    assert flips <= (850 if smooth else 40) and worst_z < (4e-3 if smooth else 1e-4) and pool_flips <= 40, \
         f"{flips} ReLU decisions differ, largest |z| there {worst_z:.2e}; {pool_flips} pool decisions differ"
     # generic position: measured 1e-5 ... 2.5e-5, gate 2e-4. Closed-form 256x256 (B=1, near-constant channels whose
     # invstd of up to 316 amplifies rounding noise; torch's own fp32 is off by 0.1 here): measured 5.9e-4 for every conv /
