@@ -224,10 +224,17 @@ class DevicePrefetcher:
     it), so the copy of batch i+2 never overwrites tensors that step i still reads.
 
     `loader`: any iterable of (images, masks) CPU tensors (make_loader(...), SeededBatches, a list). Tensors that are not
-    pinned are staged through this object's own pinned buffers."""
+    pinned are staged through this object's own pinned buffers.
+    `compact_masks`: int64 masks whose values all lie in 0..255 (class indices and the ignore value 255 of the reference's
+    VOC layout) cross the host link as uint8 — an eighth of their bytes, 9.4 instead of 16.8 MB per batch of config 2 —
+    and are widened to int64 into the device slot on the copy stream; the yielded tensors are the same int64 masks bit for
+    bit. A batch with any other value takes the plain path."""
 
-    def __init__(self, loader, device, slots: int = 2):
+    def __init__(self, loader, device, slots: int = 2, compact_masks: bool = True):
         self.loader, self.device = loader, torch.device(device)
+        self.compact_masks = compact_masks
+        self._pin_u8 = [None] * max(2, slots)
+        self._dev_u8 = [None] * max(2, slots)
         if self.device.type != "cuda":
             raise ValueError("DevicePrefetcher needs a ROCm device (there is no CPU fallback on the HIP path)")
         self.copy_stream = torch.cuda.Stream(device=self.device)
@@ -247,8 +254,22 @@ class DevicePrefetcher:
             self._dev[slot] = (torch.empty(x.shape, dtype=x.dtype, device=self.device),
                                torch.empty(y.shape, dtype=y.dtype, device=self.device))
             self._pin[slot] = None
+        compact = False
+        if self.compact_masks and y.dtype == torch.int64 and y.device.type == "cpu" and y.numel() > 0:
+            lo, hi = torch.aminmax(y)
+            compact = int(lo) >= 0 and int(hi) <= 255
+        if compact:
+            if self._pin_u8[slot] is None or self._pin_u8[slot].shape != y.shape:
+                self._pin_u8[slot] = torch.empty(y.shape, dtype=torch.uint8).pin_memory()
+                self._dev_u8[slot] = torch.empty(y.shape, dtype=torch.uint8, device=self.device)
+            if self._ready[slot] is not None:
+                self._ready[slot].synchronize()       # the previous copy out of this pinned buffer is done
+            self._pin_u8[slot].copy_(y)               # int64 -> uint8 on the host, exact for 0..255
         src = []
         for k, t in enumerate((x, y)):
+            if k == 1 and compact:
+                src.append(None)
+                continue
             if not t.is_pinned():
                 if self._pin[slot] is None:
                     self._pin[slot] = [torch.empty(x.shape, dtype=x.dtype).pin_memory(), torch.empty(y.shape, dtype=y.dtype).pin_memory()]
@@ -261,7 +282,11 @@ class DevicePrefetcher:
             if self._free[slot] is not None:
                 self.copy_stream.wait_event(self._free[slot])
             self._dev[slot][0].copy_(src[0], non_blocking=True)
-            self._dev[slot][1].copy_(src[1], non_blocking=True)
+            if compact:
+                self._dev_u8[slot].copy_(self._pin_u8[slot], non_blocking=True)
+                self._dev[slot][1].copy_(self._dev_u8[slot])          # widened on the device, on the copy stream
+            else:
+                self._dev[slot][1].copy_(src[1], non_blocking=True)
             ready = torch.cuda.Event()
             ready.record(self.copy_stream)
         self._ready[slot] = ready

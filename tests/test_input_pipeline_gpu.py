@@ -75,3 +75,26 @@ def test_prefetcher_yields_every_batch_once_in_order(dev):
         z = (x * 2).sum() / x.numel()
         seen.append((float(z) / 2, int(y.max()), tuple(x.shape)))
     assert seen == [(float(i), i, (3 if i == 6 else 4, 2, 8, 8)) for i in range(7)]
+
+
+@pytest.mark.parametrize("compact", [True, False])
+def test_mask_transport_is_exact(dev, compact):
+    """int64 masks in 0..255 cross the link as uint8 (compact_masks) and arrive as the same int64 tensors; a batch with a
+    value outside that range (-1, 300) takes the plain path; both interleaved through the same slots."""
+    import insar_unet_ca_amd as iu
+    g = torch.Generator().manual_seed(7)
+    host = []
+    for i in range(6):
+        y = torch.randint(0, 3, (4, 16, 16), generator=g, dtype=torch.int64)
+        y[:, ::5, ::3] = 255                                  # the reference's ignore value
+        if i % 3 == 1:
+            y[0, 0, 0] = -1                                   # not representable: plain path for this batch
+        if i % 3 == 2:
+            y[1, 2, 3] = 300
+        host.append((torch.randn(4, 2, 16, 16, generator=g), y))
+    pf = iu.DevicePrefetcher(host, dev, compact_masks=compact)
+    n = 0
+    for (xd, yd), (xh, yh) in zip(pf, host):
+        assert yd.dtype == torch.int64 and torch.equal(yd.cpu(), yh) and torch.equal(xd.cpu(), xh)
+        n += 1
+    assert n == 6
