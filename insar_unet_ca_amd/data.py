@@ -256,15 +256,17 @@ class DevicePrefetcher:
             self._pin[slot] = None
         compact = False
         if self.compact_masks and y.dtype == torch.int64 and y.device.type == "cpu" and y.numel() > 0:
-            lo, hi = torch.aminmax(y)
-            compact = int(lo) >= 0 and int(hi) <= 255
+            # numpy, not torch: a torch reduction wakes the whole intra-op thread pool (128 threads on a 16-core GPU box:
+            # 23 ms per call inside a training loop, against 0.17 ms for these two single-threaded passes over 1 M values)
+            yn = y.numpy()
+            compact = int(yn.min()) >= 0 and int(yn.max()) <= 255
         if compact:
             if self._pin_u8[slot] is None or self._pin_u8[slot].shape != y.shape:
                 self._pin_u8[slot] = torch.empty(y.shape, dtype=torch.uint8).pin_memory()
                 self._dev_u8[slot] = torch.empty(y.shape, dtype=torch.uint8, device=self.device)
             if self._ready[slot] is not None:
                 self._ready[slot].synchronize()       # the previous copy out of this pinned buffer is done
-            self._pin_u8[slot].copy_(y)               # int64 -> uint8 on the host, exact for 0..255
+            np.copyto(self._pin_u8[slot].numpy(), yn, casting="unsafe")     # int64 -> uint8 on the host, exact for 0..255
         src = []
         for k, t in enumerate((x, y)):
             if k == 1 and compact:
