@@ -145,6 +145,12 @@ int insar_igemm(const InsarIgemm* d, void* stream);
  * eligibility heuristic (enough tiles to fill the chip, W,H >= 30). */
 int insar_conv3x3_flat_ok(const InsarAct* x, int32_t N);
 int insar_conv3x3_flat_num_mtiles(const InsarAct* x);
+/* Row tiles (flip bit 3 = 8; bf16): a tile is 256 REAL output pixels = 256 / W whole image rows, staged with their halo
+ * pixels, so that the three dx taps share one staged tile as in the flat geometry while the tile count is M / 256 (the deep
+ * levels of the U-Net, where the flat geometry's 254-pixel step breaks the one-round-of-work-groups grid). Needs W a power
+ * of two in 16..256 and H a multiple of 256 / W: insar_conv3x3_flat_rows_ok. flip bit 4 = 16: 64-column tiles whatever N.
+ * The statistics slab has insar_conv3x3_flat_stat_rows(x, N, flip) rows, with the same bits. */
+int insar_conv3x3_flat_rows_ok(const InsarAct* x, int32_t N);
 /* rows of the statistics slab for a launch with these flags: one per M tile, or one per work-group for persistent
  * work-groups (flip bit 2) with a single N tile, which carry the sums over their tiles */
 int insar_conv3x3_flat_stat_rows(const InsarAct* x, int32_t N, int32_t flip);

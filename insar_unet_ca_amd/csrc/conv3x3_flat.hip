@@ -12,6 +12,11 @@
 //   * A ring of 2 slots (one per dy group), B ring of 3 slots (one weight slab per tap), all by untracked
 //     LDS-DMA with counted vmcnt waits; 8 waves (4 x 2), wave tile 64 x BN/2, same MFMA / swizzle /
 //     epilogue scheme as igemm.hip.
+//   * GEO = 1, "row tiles" (round 3, the deep levels: W in {16, 32, 64, 128, 256}): a tile is 256 REAL output pixels = 256 / W
+//     whole image rows, and the A slot holds those rows WITH their two halo pixels each ((256 / W) * (W + 2) <= 320 staged
+//     rows): the three dx taps still share one staged A tile, no halo pixel is computed, and the tile count is the per-tap
+//     kernel's (M / 256: exactly one round of work-groups where that kernel has one) — the flat geometry's 254-pixel step
+//     gives 275 / 292 tiles where 256 fit, and loses there to tile quantisation what it wins on operand traffic.
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
@@ -33,6 +38,7 @@ struct FlatArgs {
   int carry;                   // persistent + one N tile: BatchNorm sums carried over the tiles, slab row = blockIdx.x
   int num_mtiles, num_ntiles;
   int total_tiles;             // num_mtiles * num_ntiles
+  int lw;                      // row tiles: log2(W)
   const char* by; const float* bscale; const float* bshift;   // BatchNorm-backward sums in the stats slab (InsarBstat)
 };
 
@@ -51,13 +57,15 @@ template <> struct FMma<float> {
   }
 };
 
-template <typename T, int BN>
+#define FL_GEO1_ROWS 320                                   // staged A rows of a row tile: (256 / W) * (W + 2) <= 288, in 64-row DMA units
+template <typename T, int BN, int GEO = 0>
 struct FlatCfg {
   static constexpr int ES = sizeof(T);
   static constexpr int BKe = FL_ROWB / ES;
-  static constexpr int A_SLOT = FL_BM * FL_ROWB;          // 32 KB
+  static constexpr int A_ROWS = GEO ? FL_GEO1_ROWS : FL_BM;
+  static constexpr int A_SLOT = A_ROWS * FL_ROWB;         // 32 KB (40 KB: row tiles)
   static constexpr int B_SLOT = BN * FL_ROWB;             // 16 / 8 KB
-  static constexpr int A_DMA = FL_BM * 8 / FL_THREADS;    // 4
+  static constexpr int A_DMA = A_ROWS * 8 / FL_THREADS;   // 4 (5)
   static constexpr int B_DMA = BN * 8 / FL_THREADS;       // 2 / 1
   static constexpr int RING = 2 * A_SLOT + 3 * B_SLOT;
   static constexpr int PITCH = BN * ES + 16;
@@ -68,7 +76,7 @@ struct FlatCfg {
   // bf16, 128 columns: the kernel sits at the 256-register limit and the 16 carried BatchNorm sums of a persistent
   // work-group were spilled to scratch (17 / 22 spilled registers, reloaded and stored again at every tile); they live in
   // LDS instead, one 64-byte slot per thread (2 spills left; same-box 7.272 -> 7.256 ms/step)
-  static constexpr bool LDS_CARRY = sizeof(T) == 2 && BN == 128;
+  static constexpr bool LDS_CARRY = sizeof(T) == 2 && BN == 128 && GEO == 0;     // (row tiles: the 40 KB A slots leave no room)
   static constexpr int CARRYB = LDS_CARRY ? FL_THREADS * 2 * (16 / ES) * 4 : 0;
   static constexpr int LDS_BYTES = MAIN + ROWINFO + STATB + CARRYB;
 };
@@ -99,9 +107,9 @@ __device__ __forceinline__ void fl_wait_and_barrier() {
 // one phase after it was issued and read one phase after that wait. Same accumulation order as the plain loop.
 // BS: BatchNorm-backward sums in the statistics slab (InsarBstat; an instantiation of its own: the 128-column kernel is
 // at the register limit and the plain launches keep their code).
-template <typename T, int BN, bool PP = false, bool BS = false>
+template <typename T, int BN, bool PP = false, bool BS = false, int GEO = 0>
 __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a) {
-  using Cfg = FlatCfg<T, BN>;
+  using Cfg = FlatCfg<T, BN, GEO>;
   constexpr int ES = Cfg::ES, BKe = Cfg::BKe, CH = Chunk<T>::N;
   constexpr int NT = BN / 32, MT = 4;
   constexpr int AD = Cfg::A_DMA, BD = Cfg::B_DMA;
@@ -145,6 +153,17 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
 
   // output offsets of the tile's rows: computed AFTER the first LDS-DMA pieces are issued (below), under their flight
   auto fill_row_out = [&]() {
+    if constexpr (GEO == 1) {
+      if (tid < FL_BM) {                                      // every row of a row tile is a real output pixel
+        const int hw = a.H * a.W;
+        const long long m = (long long)mtile * FL_BM + tid;
+        const int n = (int)(m / hw);
+        const int rem = (int)(m - (long long)n * hw);
+        const int h = rem / a.W, wcol = rem - h * a.W;
+        rowOut[tid] = ((long long)(n * (a.H + 2) + h + 1) * Wp + wcol + 1) * a.Cy + a.cy_off;
+      }
+      return;
+    }
     if (tid < FL_BM) {
       const int q = (int)q0 + tid;                            // P < 2^31 (checked by the host side)
       long long ro = -1;
@@ -163,8 +182,24 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
   const int srow = tid >> 3;                                 // + 64*i
   const int schunk = ((tid & 7) ^ (srow & 7)) * 16;
   int a_pix[AD];
+  if constexpr (GEO == 1) {
+    // staged row L = ir * (W + 2) + c: padded column c of the tile's image row ir (dy = 0; stageA adds the dy shift)
+    const int S = (FL_BM / a.W) * Wp;
+    const long long m0 = (long long)mtile * FL_BM;
+    const int hw = a.H * a.W;
+    const int n0i = (int)(m0 / hw);
+    const int h0 = (int)(m0 - (long long)n0i * hw) / a.W;
 #pragma unroll
-  for (int i = 0; i < AD; ++i) a_pix[i] = (int)q0 + srow + 64 * i;
+    for (int i = 0; i < AD; ++i) {
+      int L = srow + 64 * i;
+      L = L < S ? L : S - 1;                                  // rows beyond the staged span: the last one again
+      const int ir = L / Wp, c = L - ir * Wp;
+      a_pix[i] = (n0i * (a.H + 2) + h0 + ir + 1) * Wp + c;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < AD; ++i) a_pix[i] = (int)q0 + srow + 64 * i;
+  }
   const char* xbase = a.x + (long long)a.cx_off * ES + schunk;
   const long long xpitch = (long long)a.Cx * ES;
   const char* wbase = a.w + ((long long)(n0 + srow) * a.K) * ES + schunk;
@@ -201,7 +236,9 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
   const int b_frag = (wn * (BN / 2) + r16) * FL_ROWB;
   const int swb = r16 & 7;
   const int arow0 = wm * 64 + r16;
-
+  // row tiles: pixel m = arow0 + 16 * mt of the tile sits in staged row m + 2 * (m / W) + 1 (two halo pixels per image row
+  // before it, one at the head of its own row); tap dx reads one row further per step. W is a power of two >= 16: a 16-pixel
+  // fragment never leaves its image row.
   const int kcs = a.kc_count;
   const int nsteps = kcs * 9, ngroups = kcs * 3;
 
@@ -235,8 +272,14 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
           for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-              int row = arow0 + mt * 16 + (dxi - 1);
-              row = row < 0 ? 0 : (row > FL_BM - 1 ? FL_BM - 1 : row);
+              int row;
+              if constexpr (GEO == 1) {
+                const int m = arow0 + mt * 16;
+                row = m + ((m >> a.lw) << 1) + dxi;
+              } else {
+                row = arow0 + mt * 16 + (dxi - 1);
+                row = row < 0 ? 0 : (row > FL_BM - 1 ? FL_BM - 1 : row);
+              }
               xf[sub][mt] = *(const uint4*)(sA + row * FL_ROWB + (((kq + 4 * sub) ^ (row & 7)) << 4));
             }
             const int pcb = ((kq + 4 * sub) ^ swb) << 4;
@@ -306,8 +349,14 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
           uint4 xf[MT], wf[NT];
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            int row = arow0 + mt * 16 + (dxi - 1);
-            row = row < 0 ? 0 : (row > FL_BM - 1 ? FL_BM - 1 : row);
+            int row;
+            if constexpr (GEO == 1) {
+              const int m = arow0 + mt * 16;
+              row = m + ((m >> a.lw) << 1) + dxi;
+            } else {
+              row = arow0 + mt * 16 + (dxi - 1);
+              row = row < 0 ? 0 : (row > FL_BM - 1 ? FL_BM - 1 : row);
+            }
             xf[mt] = *(const uint4*)(sA + row * FL_ROWB + (((kq + 4 * sub) ^ (row & 7)) << 4));
           }
           const int pcb = ((kq + 4 * sub) ^ swb) << 4;
@@ -404,7 +453,7 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
       }
     }
   }
-  if (a.stats && a.carry) {
+  if (GEO == 0 && a.stats && a.carry) {            // (row tiles never carry: one slab row per tile)
     if constexpr (Cfg::LDS_CARRY) {
       // same sums in the same order as the register carry: slot j of the thread += this tile's sum
 #pragma unroll
@@ -449,7 +498,7 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
   __syncthreads();          // the next tile's LDS-DMA rewrites the ring the epilogue tile aliases
   FL_STAMP(6);          // the other waves' epilogues
   }
-  if (a.stats && a.carry) {
+  if (GEO == 0 && a.stats && a.carry) {
     constexpr int CPR = BN * ES / 16;
     constexpr int CH = CHc;
     if constexpr (Cfg::LDS_CARRY) {
@@ -503,24 +552,35 @@ extern "C" int insar_conv3x3_flat_ok(const InsarAct* x, int32_t N) {
   return (long long)flat_mtiles(P) * (N / bn) >= 256 ? 1 : 0;
 }
 extern "C" int insar_conv3x3_flat_num_mtiles(const InsarAct* x) { return x ? flat_mtiles(flat_pixels(*x)) : 0; }
+// Row tiles (flip bit 3): 256 real output pixels = 256 / W whole image rows per tile. bf16, W a power of two in 16 .. 256,
+// H a multiple of 256 / W (a tile never straddles two images).
+static inline bool flat_rows_geometry(const InsarAct& x) {
+  if (x.dtype != INSAR_BF16) return false;
+  if (x.W < 16 || x.W > FL_BM || (FL_BM % x.W) != 0 || (x.W & (x.W - 1)) != 0) return false;
+  if (x.H % (FL_BM / x.W)) return false;
+  return flat_pixels(x) < 0x7fffffffLL;
+}
+extern "C" int insar_conv3x3_flat_rows_ok(const InsarAct* x, int32_t N) {
+  return (x && (N % 64) == 0 && (x->c_len % 64) == 0 && flat_rows_geometry(*x)) ? 1 : 0;
+}
 // Rows of the statistics slab a launch with these flags writes: one per M tile, or — persistent work-groups (flip bit 2)
 // with one N tile — one per work-group.
 extern "C" int insar_conv3x3_flat_stat_rows(const InsarAct* x, int32_t N, int32_t flip) {
   if (!x) return 0;
-  const int mt = flat_mtiles(flat_pixels(*x));
-  if (!(flip & 4)) return mt;
-  const int bn = (N % 128) == 0 ? 128 : 64;
+  const int mt = (flip & 8) ? (int)(((long long)x->B * x->H * x->W) / FL_BM) : flat_mtiles(flat_pixels(*x));
+  if (!(flip & 4) || (flip & 8)) return mt;
+  const int bn = ((N % 128) == 0 && !(flip & 16)) ? 128 : 64;
   const int cus = insar_num_cus() & ~7;
   const long long grid = (long long)mt * (N / bn);
   return (cus >= 8 && grid > cus && N / bn == 1) ? cus : mt;
 }
 
-template <typename T, int BN, bool PP = false, bool BS = false>
+template <typename T, int BN, bool PP = false, bool BS = false, int GEO = 0>
 static int launch_flat(FlatArgs& a, hipStream_t s) {
-  using Cfg = FlatCfg<T, BN>;
+  using Cfg = FlatCfg<T, BN, GEO>;
   static std::atomic<uint64_t> attr_mask{0};     // per-device, see common.h
   {
-    hipError_t e = insar_set_lds_once(attr_mask, (const void*)conv3x3_flat_kernel<T, BN, PP, BS>, Cfg::LDS_BYTES);
+    hipError_t e = insar_set_lds_once(attr_mask, (const void*)conv3x3_flat_kernel<T, BN, PP, BS, GEO>, Cfg::LDS_BYTES);
     if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_conv3x3_flat: hipFuncSetAttribute(%d bytes LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
   }
   a.num_ntiles = a.N / BN;
@@ -529,9 +589,9 @@ static int launch_flat(FlatArgs& a, hipStream_t s) {
   a.carry = 0;
   if (a.persist) {                                   // one work-group per CU (the LDS allows no more), each walking its tiles
     const int cus = insar_num_cus() & ~7;
-    if (cus >= 8 && grid > cus) { grid = cus; a.carry = a.num_ntiles == 1 ? 1 : 0; }
+    if (cus >= 8 && grid > cus) { grid = cus; a.carry = (a.num_ntiles == 1 && GEO == 0) ? 1 : 0; }
   }
-  hipLaunchKernelGGL((conv3x3_flat_kernel<T, BN, PP, BS>), dim3((unsigned)grid), dim3(FL_THREADS), Cfg::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((conv3x3_flat_kernel<T, BN, PP, BS, GEO>), dim3((unsigned)grid), dim3(FL_THREADS), Cfg::LDS_BYTES, s, a);
   INSAR_CHECK_LAUNCH("insar_conv3x3_flat");
   return INSAR_OK;
 }
@@ -562,14 +622,22 @@ static int flat_impl(const InsarAct* x, const InsarAct* y, const void* w, int32_
     if (!insar_aligned16(bstat->y)) INSAR_FAIL(INSAR_E_ALIGN, "insar_conv3x3_flat_bstat: bstat.y not 16-byte aligned");
     a.by = (const char*)bstat->y; a.bscale = bstat->scale; a.bshift = bstat->shift;
   }
-  a.P = P; a.B = x->B; a.H = x->H; a.W = x->W;
+  a.P = P; a.B = x->B; a.H = x->H; a.W = x->W; a.lw = 0;
   a.Cx = x->C; a.cx_off = x->c_off; a.K = x->c_len;
   a.Cy = y->C; a.cy_off = y->c_off; a.N = y->c_len;
   a.kc_count = x->c_len / bke; a.flip = (flip & 1) ? 1 : 0; a.persist = (flip & 4) ? 1 : 0;
   const bool pp = (flip & 2) != 0;
   a.num_mtiles = flat_mtiles(P);
   hipStream_t s = (hipStream_t)stream;
-  const bool wide = (a.N % 128) == 0;
+  const bool wide = (a.N % 128) == 0 && !(flip & 16);      // bit 4: 64-column tiles whatever N (grids of 256 work-groups on the 16^2 level)
+  if (flip & 8) {       // row tiles (bf16, ping-pong loop)
+    if (!flat_rows_geometry(*x)) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: row tiles need bf16, W a power of two in 16..256 and H a multiple of 256 / W (got %d x %d)", x->H, x->W);
+    a.num_mtiles = (int)(((long long)x->B * x->H * x->W) / FL_BM);
+    a.lw = 0;
+    while ((1 << a.lw) < x->W) ++a.lw;
+    if (a.by) return wide ? launch_flat<bf16_t, 128, true, true, 1>(a, s) : launch_flat<bf16_t, 64, true, true, 1>(a, s);
+    return wide ? launch_flat<bf16_t, 128, true, false, 1>(a, s) : launch_flat<bf16_t, 64, true, false, 1>(a, s);
+  }
   if (a.by) {           // bf16: the ping-pong loop whatever the flag says (same results bit for bit)
     if (x->dtype == INSAR_BF16) return wide ? launch_flat<bf16_t, 128, true, true>(a, s) : launch_flat<bf16_t, 64, true, true>(a, s);
     return wide ? launch_flat<float, 128, false, true>(a, s) : launch_flat<float, 64, false, true>(a, s);

@@ -341,6 +341,10 @@ IGEMM_PP = int(os.environ.get("INSAR_IGEMM_PP", "1"))            # 256 x 256 til
 # up to it the finalize launch folds the slab itself (16 row lanes x 8 rows in flight: 1024 rows are 8 round trips, cheaper
 # than the extra launch on the forward chain)
 STAT_PREFOLD_ROWS = int(os.environ.get("INSAR_STAT_PREFOLD_ROWS", "1024"))
+# 3x3 convs the per-tap kernel would run on 256 x 128 / 256 x 64 tiles (the 32^2 and 16^2 levels, the 128-column layers of the
+# 64^2 / 128^2 levels) go to the flat kernel's row-tile geometry instead (the dx taps share one staged A tile, same tile count:
+# 12-24 % faster per launch, tools/gemm_bench.py --what rows -> profiles/r03_row_tiles.txt). 0 = per-tap kernel everywhere.
+FLAT_ROWS = os.environ.get("INSAR_FLAT_ROWS", "1") != "0"
 BSTAT_FUSE = os.environ.get("INSAR_BSTAT_FUSE", "1") != "0"      # diagnostic: 0 = BatchNorm-backward sums always in a pass of their own
 BSTAT_C64 = os.environ.get("INSAR_BSTAT_C64", "1") != "0"       # the 64 -> 64 kernel's variant of it. Alone it costs more than it saves (8-byte y loads from the accumulator layout: 89 -> 140 us per launch against the 43 us reduce pass it replaces), in the step it wins (same-box A/B 7.70 -> 7.61 ms: one launch less on the dgrad chain beside the weight-gradient stream)
 WGRAD_LATE = os.environ.get("INSAR_WGRAD_ORDER", "before") == "after"      # diagnostic / tuning switch, see ConvBN.backward
@@ -393,8 +397,21 @@ def _flat_persist(flip: int) -> bool:
     return FLAT_PERSIST == 2 or (FLAT_PERSIST == 1 and not (flip & 1))
 
 
-def _conv3x3_flat(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[torch.Tensor], bstat=None) -> None:
-    flags = flip | (2 if FLAT_PP else 0) | (4 if _flat_persist(flip) else 0)
+def _rows_flags(x: Act, N: int) -> int:
+    """flip bits (8 | 16) of the flat kernel's row-tile geometry for a 3x3 conv of x's grid to N channels, or 0 where the
+    per-tap kernel keeps the layer: fp32, grids the geometry does not cover, and wherever the per-tap kernel runs its
+    256 x 256 ping-pong tiles (it wins there). 64-column tiles (bit 4) where 128-column ones would give fewer than 256."""
+    if not FLAT_ROWS or x.code != _lib.BF16 or not call("insar_conv3x3_flat_rows_ok", x.ref, N):
+        return 0
+    M = x.B * x.H * x.W
+    if call("insar_igemm_tile_cols_dt", M, N, x.code) == 256:
+        return 0
+    narrow = (N % 128) != 0 or (M // 256) * (N // 128) < 256
+    return 8 | (16 if narrow else 0)
+
+
+def _conv3x3_flat(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[torch.Tensor], bstat=None, geo: int = 0) -> None:
+    flags = flip | (2 if (FLAT_PP or geo) else 0) | (4 if (_flat_persist(flip) and not geo) else 0) | geo
     if bstat is not None:
         bs = _lib.InsarBstat(bstat[0].buf.data_ptr(), ptr(bstat[1]), ptr(bstat[2]))
         fn = lambda: call("insar_conv3x3_flat_bstat", x.ref, y.ref, ptr(w), flags, ptr(stats), C.byref(bs), _lib.stream_ptr())
@@ -402,8 +419,9 @@ def _conv3x3_flat(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[to
         fn = lambda: call("insar_conv3x3_flat", x.ref, y.ref, ptr(w), flags, ptr(stats), _lib.stream_ptr())
     if PROFILER is not None:
         flops = 2.0 * x.B * x.H * x.W * y.c_len * x.c_len * 9
-        tag = "conv3x3_flat_kernel<%s, %d>%s" % ("float" if x.code == _lib.F32 else "bf16_t", 128 if y.c_len % 128 == 0 else 64,
-                                                 " +bstat" if bstat is not None else "")
+        tag = "conv3x3_flat_kernel<%s, %d>%s%s" % ("float" if x.code == _lib.F32 else "bf16_t",
+                                                   128 if (y.c_len % 128 == 0 and not (geo & 16)) else 64,
+                                                   " row tiles" if geo else "", " +bstat" if bstat is not None else "")
         PROFILER.run(tag, flops, fn)
         return
     fn()
@@ -573,8 +591,14 @@ class ConvBN:
         self.c64_fwd, self.c64_bwd = self.c64 and c64_mode != "bwd", self.c64 and c64_mode != "fwd"
         self.flat_fwd = (not self.small) and not self.c64 and bool(call("insar_conv3x3_flat_ok", x.ref, self.cout))
         self.flat_bwd = (not self.small) and not self.c64 and bool(call("insar_conv3x3_flat_ok", x.ref, self.cin))
+        # the rest: per-tap implicit GEMM, or (bf16, where that kernel would not run its 256 x 256 tiles) the flat kernel's row tiles
+        plain = not (self.small or self.c64)
+        self.rows_fwd = _rows_flags(x, self.cout) if (plain and not self.flat_fwd) else 0
+        self.rows_bwd = _rows_flags(x, self.cin) if (plain and not self.flat_bwd) else 0
         if self.small:
             self.stat_rows = call("insar_conv3x3_small_fwd_rows", x.ref, self.y.ref)
+        elif self.rows_fwd:
+            self.stat_rows = call("insar_conv3x3_flat_stat_rows", x.ref, self.cout, self.rows_fwd)
         elif self.c64_fwd:
             self.stat_rows = call("insar_conv3x3_c64_rows", x.ref)
         elif self.c64:
@@ -642,6 +666,9 @@ class ConvBN:
         elif self.flat_fwd:
             self.ctx.join_side()
             _conv3x3_flat(self.x, self.y, self.w.fwd(), 0, self.stats if training else None)
+        elif self.rows_fwd:
+            self.ctx.join_side()
+            _conv3x3_flat(self.x, self.y, self.w.fwd(), 0, self.stats if training else None, geo=self.rows_fwd)
         else:
             self.ctx.join_side()
             _igemm(self.x, self.y, self.w.fwd(), self.cout, self.x.H, self.x.W, 1, _TAPS3, 0,
@@ -826,6 +853,14 @@ class ConvBN:
                     bstat_for.bred_ready = True
                 else:
                     _conv3x3_flat(self.dy, dx, self.w.dgrad(), 1, None)
+            elif self.rows_bwd:
+                # row tiles are whole image rows of ONE image: the slab rows group per image, as an SE consumer needs
+                slab = None
+                if bstat_for is not None and BSTAT_FUSE and _same_layout(dx, bstat_for.y):
+                    slab = bstat_for.bstat_slab(call("insar_conv3x3_flat_stat_rows", self.dy.ref, self.cin, self.rows_bwd), bstat_se)
+                _conv3x3_flat(self.dy, dx, self.w.dgrad(), 1, slab[0] if slab else None, bstat=slab[1] if slab else None, geo=self.rows_bwd)
+                if slab:
+                    bstat_for.bred_ready = True
             else:
                 slab = _igemm_bstat_slab(bstat_for, bstat_se, self.M, self.cin, H * W, dx)
                 _igemm(self.dy, dx, self.w.dgrad(), self.cin, H, W, 1, _TAPS3_DGRAD, 0,

@@ -230,6 +230,50 @@ def test_conv3x3_flat_against_float64(dev, dtype, cin, cout, shape):
     assert _halo_abs(dxa) == 0.0
 
 
+@pytest.mark.parametrize("cin,cout,shape,narrow", [
+    (128, 128, (2, 128, 32, 32), False),     # 8 image rows per tile, one N tile
+    (256, 64, (4, 256, 16, 16), False),      # a tile = one whole 16 x 16 image, four K slabs per tap
+    (64, 256, (1, 64, 64, 64), False),       # 4 rows per tile, two N tiles of 128
+    (128, 256, (2, 128, 16, 16), True),      # 64-column tiles although N is a multiple of 128 (flag bit 4)
+    (64, 64, (1, 64, 4, 128), False),        # two rows per tile
+    (64, 128, (2, 64, 3, 256), False),       # one row per tile
+])
+def test_conv3x3_flat_row_tiles_against_float64(dev, cin, cout, shape, narrow):
+    """The flat kernel's row-tile geometry (flip bit 3: 256 real pixels = whole image rows per tile, staged with their
+    halo pixels; the three dx taps share the staged tile): forward with BatchNorm partial sums and input gradient
+    against float64 on the kernel's own operands, bit for bit the flat geometry's output."""
+    from insar_unet_ca_amd import _lib, engine
+    from insar_unet_ca_amd._lib import call, ptr
+    dtype = torch.bfloat16
+    ctx = engine.Ctx(dev, dtype)
+    b, _, h, w = shape
+    xa = _act_from(cf.make_input(shape), dtype, dev)
+    assert call("insar_conv3x3_flat_rows_ok", xa.ref, cout) == 1
+    ya, yb = (engine.Act.alloc(b, h, w, cout, dtype, dev) for _ in range(2))
+    p = torch.nn.Parameter(cf.fill_tensor("weight", (cout, cin, 3, 3), 11).to(dev))
+    gw = engine.GemmWeight(ctx, p, "conv3")
+    flags = 8 | 2 | (16 if narrow else 0)
+    rows = call("insar_conv3x3_flat_stat_rows", xa.ref, cout, flags)
+    assert rows == b * h * w // 256
+    stats = torch.zeros(rows, 2, cout, device=dev)
+    call("insar_conv3x3_flat", xa.ref, ya.ref, ptr(gw.fwd()), flags, ptr(stats), _lib.stream_ptr())
+    xr = xa.nchw().cpu().double()
+    wr = gw.fwd().float().cpu().reshape(3, 3, cout, cin).permute(2, 3, 0, 1).double()
+    assert max_rel(ya.nchw(), F.conv2d(xr, wr, padding=1)) <= 6e-3
+    assert _halo_abs(ya) == 0.0
+    got = ya.nchw().double().cpu()
+    assert max_rel(stats.sum(0)[0], got.sum((0, 2, 3))) <= 1e-4
+    assert max_rel(stats.sum(0)[1], (got ** 2).sum((0, 2, 3))) <= 1e-4
+    # same products in the same order as the flat geometry: identical output
+    call("insar_conv3x3_flat", xa.ref, yb.ref, ptr(gw.fwd()), 2, 0, _lib.stream_ptr())
+    assert torch.equal(ya.buf, yb.buf)
+    ga = _act_from(cf.make_grad((b, cout, h, w)), dtype, dev)
+    dxa = engine.Act.alloc(b, h, w, cin, dtype, dev)
+    call("insar_conv3x3_flat", ga.ref, dxa.ref, ptr(gw.dgrad()), flags | 1, 0, _lib.stream_ptr())
+    assert max_rel(dxa.nchw(), F.conv_transpose2d(ga.nchw().cpu().double(), wr, padding=1)) <= 6e-3
+    assert _halo_abs(dxa) == 0.0
+
+
 @pytest.mark.parametrize("shape", [
     (2, 64, 40, 56),       # several tiles, short rows
     (1, 64, 33, 300),      # rows longer than a tile

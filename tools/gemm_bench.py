@@ -10,6 +10,7 @@ LAYERS = {  # name: (cin, cout, hw)
     "inc.3": (64, 64, 256), "down1.0": (64, 128, 128), "down1.3": (128, 128, 128), "down2.3": (256, 256, 64),
     "down3.3": (512, 512, 32), "down4.3": (1024, 1024, 16), "conv1.0": (1024, 512, 32), "conv2.0": (512, 256, 64),
     "conv3.0": (256, 128, 128), "conv4.0": (128, 64, 256),
+    "down2.0": (128, 256, 64), "down3.0": (256, 512, 32), "down4.0": (512, 1024, 16), "conv1.3": (512, 512, 32), "conv2.3": (256, 256, 64),
 }
 
 def main():
@@ -95,6 +96,21 @@ def main():
             for pb in (0, 4):
                 f = sorted(v[0] for v in rr[pb]); d = sorted(v[1] for v in rr[pb])
                 res.append(f"\n   persist={pb >> 2}: fwd min {f[0]:6.1f} med {f[len(f)//2]:6.1f} us  dgrad min {d[0]:6.1f} med {d[len(d)//2]:6.1f} us")
+        if "rows" in what:     # per-tap igemm against the flat kernel's row tiles (flip bit 3), same process, interleaved rounds
+            from insar_unet_ca_amd._lib import ptr
+            if call("insar_conv3x3_flat_rows_ok", x.ref, cout) and call("insar_conv3x3_flat_rows_ok", g.ref, cin):
+                for narrow in (0, 16):
+                    fl = 8 | 2 | narrow
+                    st3 = torch.zeros(call("insar_conv3x3_flat_stat_rows", x.ref, cout, fl), 2, cout, device=dev)
+                    rr = {"igemm": [], "rows": []}
+                    for r in range(4):
+                        rr["igemm"].append((run(lambda: engine._igemm(x, y, wf, cout, hw, hw, 1, engine._TAPS3, 0, stats=stats)),
+                                            run(lambda: engine._igemm(g, dx, wd, cin, hw, hw, 1, engine._TAPS3_DGRAD, 0))))
+                        rr["rows"].append((run(lambda: call("insar_conv3x3_flat", x.ref, y.ref, ptr(wf), fl, ptr(st3), _lib.stream_ptr())),
+                                           run(lambda: call("insar_conv3x3_flat", g.ref, dx.ref, ptr(wd), fl | 1, 0, _lib.stream_ptr()))))
+                    for k in ("igemm", "rows"):
+                        f = sorted(v[0] for v in rr[k]); d = sorted(v[1] for v in rr[k])
+                        res.append(f"\n   {k:5s} narrow={narrow >> 4}: fwd min {f[0]:6.1f} med {f[len(f)//2]:6.1f} us ({flops/f[0]/1e6:5.0f} TF)  dgrad min {d[0]:6.1f} med {d[len(d)//2]:6.1f} us ({flops/d[0]/1e6:5.0f} TF)")
         if "flat" in what:
             from insar_unet_ca_amd._lib import ptr
             rows = call("insar_conv3x3_flat_num_mtiles", x.ref)
