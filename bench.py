@@ -207,7 +207,7 @@ def measure(args, world: int, rank: int, dev, dist, iu, engine, make_batch):
 
     # Roofline leg: the same K steps twice more, in the same process, with a HIP-event pair around every GEMM-class
     # launch, recorded on the stream the kernel is launched on (main or side). Pass 1 keeps the launch configuration
-    # of the timed region (weight gradients on the side stream beside the dgrad chain, split-K for half the slots);
+    # of the timed region (weight gradients on the side stream beside the dgrad chain, split-K for 0.6 of the work-group slots);
     # pass 2 runs everything on ONE stream (each kernel alone on the chip, split-K that fills it). Both are kept out
     # of the timed region above because ~130 event records per step cost host time and perturb the overlap.
     timers = {}
@@ -329,7 +329,7 @@ def measure(args, world: int, rank: int, dev, dist, iu, engine, make_batch):
                                "avg_launch_us": round(al["avg_us"], 2)} if al else None),
                     "measured": "HIP events around each launch on the stream it is launched on, in a second pass of the "
                                 "same %d steps in the launch configuration of the timed region (weight gradients on the "
-                                "side stream beside the dgrad chain, split-K for half the work-group slots: kernels that "
+                                "side stream beside the dgrad chain, split-K for 0.6 of the work-group slots: kernels that "
                                 "overlap share the chip, so their durations are longer than alone; %.2f ms/step with "
                                 "events vs %.2f ms/step timed); `alone` = a third pass on ONE stream, every kernel by "
                                 "itself on the chip (%.2f ms/step); compare profiles/ kernel stats; traffic = rocprofv3 "

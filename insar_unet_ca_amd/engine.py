@@ -330,9 +330,9 @@ WGRAD_GRID_CAP = int(os.environ.get("INSAR_WGRAD_GRID_CAP", "200"))    # 8-wave 
 COEF_FUSE = os.environ.get("INSAR_COEF_FUSE", "1") != "0"        # diagnostic: 0 = two launches for the coefficient stages of every unit
 COEF_SIMPLE = os.environ.get("INSAR_COEF_SIMPLE", "1") != "0"    # units without an SE gate: the channel-parallel one-launch kernel (0 = the ticket kernel)
 OUTC_WGRAD_FUSE = os.environ.get("INSAR_OUTC_WGRAD_FUSE", "1") != "0"   # diagnostic: 0 = outc's weight gradient in its own pass over y
-WGRAD_FILL_T = float(os.environ.get("INSAR_WGRAD_FILL_T", "0.5"))   # the same for the transposed convs' per-tap weight gradient
+WGRAD_FILL_T = float(os.environ.get("INSAR_WGRAD_FILL_T", "0.7"))   # the same for the transposed convs' per-tap weight gradient
 WGRAD_FILL_ALONE = float(os.environ.get("INSAR_WGRAD_FILL_ALONE", "1.0"))   # ... and when it has the GPU to itself
-WGRAD_FILL = float(os.environ.get("INSAR_WGRAD_FILL", "0.5"))     # share of the work-group slots a side-stream weight gradient aims at
+WGRAD_FILL = float(os.environ.get("INSAR_WGRAD_FILL", "0.6"))     # share of the work-group slots a side-stream weight gradient aims at (0.5 until the row tiles made the dgrad chain faster: re-swept, 0.55-0.65 with 0.7 for the transposed convs is 0.09 ms better, profiles/r03_row_tiles.txt)
 WGRAD_ROWS = os.environ.get("INSAR_WGRAD_ROWS", "1") != "0"      # diagnostic: 0 = per-tap weight-gradient kernel everywhere
 FLAT_PP = int(os.environ.get("INSAR_FLAT_PP", "1"))               # flat 3x3 kernel: ping-pong tap steps (0 = plain loop; bitwise equal)
 FLAT_PERSIST = int(os.environ.get("INSAR_FLAT_PERSIST", "2"))     # flat 3x3 kernel: one work-group per CU walking its tiles (bitwise equal): 1 = forward launches, 2 = all (default since round 3: with the BatchNorm-backward sums carried over a work-group's tiles the input-gradient launches gain too, same-box 7.55 -> 7.49 ms/step), 0 = off
