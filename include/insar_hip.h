@@ -151,6 +151,9 @@ int insar_conv3x3_flat_num_mtiles(const InsarAct* x);
  * of two in 16..256 and H a multiple of 256 / W: insar_conv3x3_flat_rows_ok. flip bit 4 = 16: 64-column tiles whatever N.
  * The statistics slab has insar_conv3x3_flat_stat_rows(x, N, flip) rows, with the same bits. */
 int insar_conv3x3_flat_rows_ok(const InsarAct* x, int32_t N);
+/* Row tiles of a DILATED 3x3 convolution (padding = dilation; flip bits 8-11 carry the dilation, 0 = 1): taps that reach beyond
+ * the one-pixel halo read zeros, as insar_igemm's INSAR_IGEMM_OOB_ZERO. Needs 256 / W * (W + 2 * dil) <= 320 besides the above. */
+int insar_conv3x3_flat_rows_dil_ok(const InsarAct* x, int32_t N, int32_t dil);
 /* rows of the statistics slab for a launch with these flags: one per M tile, or one per work-group for persistent
  * work-groups (flip bit 2) with a single N tile, which carry the sums over their tiles */
 int insar_conv3x3_flat_stat_rows(const InsarAct* x, int32_t N, int32_t flip);

@@ -39,6 +39,7 @@ struct FlatArgs {
   int num_mtiles, num_ntiles;
   int total_tiles;             // num_mtiles * num_ntiles
   int lw;                      // row tiles: log2(W)
+  int dil;                     // dilated row tiles (GEO = 2): dilation of the 3x3 taps; taps beyond the one-pixel halo read zeros
   const char* by; const float* bscale; const float* bshift;   // BatchNorm-backward sums in the stats slab (InsarBstat)
 };
 
@@ -62,7 +63,7 @@ template <typename T, int BN, int GEO = 0>
 struct FlatCfg {
   static constexpr int ES = sizeof(T);
   static constexpr int BKe = FL_ROWB / ES;
-  static constexpr int A_ROWS = GEO ? FL_GEO1_ROWS : FL_BM;
+  static constexpr int A_ROWS = GEO ? FL_GEO1_ROWS : FL_BM;         // GEO: 0 flat pixel space, 1 row tiles, 2 row tiles of a dilated conv
   static constexpr int A_SLOT = A_ROWS * FL_ROWB;         // 32 KB (40 KB: row tiles)
   static constexpr int B_SLOT = BN * FL_ROWB;             // 16 / 8 KB
   static constexpr int A_DMA = A_ROWS * 8 / FL_THREADS;   // 4 (5)
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
 
   // output offsets of the tile's rows: computed AFTER the first LDS-DMA pieces are issued (below), under their flight
   auto fill_row_out = [&]() {
-    if constexpr (GEO == 1) {
+    if constexpr (GEO >= 1) {
       if (tid < FL_BM) {                                      // every row of a row tile is a real output pixel
         const int hw = a.H * a.W;
         const long long m = (long long)mtile * FL_BM + tid;
@@ -182,7 +183,32 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
   const int srow = tid >> 3;                                 // + 64*i
   const int schunk = ((tid & 7) ^ (srow & 7)) * 16;
   int a_pix[AD];
-  if constexpr (GEO == 1) {
+  unsigned a_ok = 0;                 // dilated row tiles: bit 3 i + dyi = piece i of kernel row dyi reads a real (or halo) pixel, else the zero pixel
+  if constexpr (GEO == 2) {
+    // as GEO = 1 below with d columns either side of an image row: staged row L = ir * (W + 2 d) + c is column c - d of the
+    // tile's image row ir. Taps that reach beyond the one-pixel halo of the activation buffers are read from pixel 0 of the
+    // buffer — the top-left halo pixel, zero in every channel (as the per-tap kernel's OOB variant does).
+    const int d = a.dil, Ws = a.W + 2 * d;
+    const int S = (FL_BM / a.W) * Ws;
+    const long long m0 = (long long)mtile * FL_BM;
+    const int hw = a.H * a.W;
+    const int n0i = (int)(m0 / hw);
+    const int h0 = (int)(m0 - (long long)n0i * hw) / a.W;
+#pragma unroll
+    for (int i = 0; i < AD; ++i) {
+      int L = srow + 64 * i;
+      L = L < S ? L : S - 1;
+      const int ir = L / Ws, c = L - ir * Ws;
+      const int win = c - d;                                  // input column, -d .. W + d - 1
+      a_pix[i] = (n0i * (a.H + 2) + h0 + ir + 1) * Wp + win + 1;
+      const bool colok = win >= -1 && win <= a.W;
+#pragma unroll
+      for (int dyi = 0; dyi < 3; ++dyi) {
+        const int hin = h0 + ir + (dyi - 1) * d;
+        if (colok && hin >= -1 && hin <= a.H) a_ok |= 1u << (3 * i + dyi);
+      }
+    }
+  } else if constexpr (GEO == 1) {
     // staged row L = ir * (W + 2) + c: padded column c of the tile's image row ir (dy = 0; stageA adds the dy shift)
     const int S = (FL_BM / a.W) * Wp;
     const long long m0 = (long long)mtile * FL_BM;
@@ -209,11 +235,12 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
   const uint32_t ldsB = ldsA + 2 * Cfg::A_SLOT;
 
   auto stageA = [&](int slot, int kc, int dyi) {
-    const int shift = (dyi - 1) * Wp;
+    const int shift = (dyi - 1) * Wp * (GEO == 2 ? a.dil : 1);
     const long long koff = (long long)kc * BKe * ES;
 #pragma unroll
     for (int i = 0; i < AD; ++i) {
       int pix = a_pix[i] + shift;
+      if constexpr (GEO == 2) pix = ((a_ok >> (3 * i + dyi)) & 1u) ? pix : 0;
       pix = pix < 0 ? 0 : (pix > Pm1 ? Pm1 : pix);
       lds_dma16_untracked(xbase + (long long)pix * xpitch + koff, ldsA + slot * Cfg::A_SLOT + i * (FL_THREADS * 16));
     }
@@ -273,7 +300,10 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
               int row;
-              if constexpr (GEO == 1) {
+              if constexpr (GEO == 2) {
+                const int m = arow0 + mt * 16;
+                row = m + (m >> a.lw) * (2 * a.dil) + dxi * a.dil;
+              } else if constexpr (GEO == 1) {
                 const int m = arow0 + mt * 16;
                 row = m + ((m >> a.lw) << 1) + dxi;
               } else {
@@ -350,7 +380,10 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             int row;
-            if constexpr (GEO == 1) {
+            if constexpr (GEO == 2) {
+              const int m = arow0 + mt * 16;
+              row = m + (m >> a.lw) * (2 * a.dil) + dxi * a.dil;
+            } else if constexpr (GEO == 1) {
               const int m = arow0 + mt * 16;
               row = m + ((m >> a.lw) << 1) + dxi;
             } else {
@@ -554,14 +587,20 @@ extern "C" int insar_conv3x3_flat_ok(const InsarAct* x, int32_t N) {
 extern "C" int insar_conv3x3_flat_num_mtiles(const InsarAct* x) { return x ? flat_mtiles(flat_pixels(*x)) : 0; }
 // Row tiles (flip bit 3): 256 real output pixels = 256 / W whole image rows per tile. bf16, W a power of two in 16 .. 256,
 // H a multiple of 256 / W (a tile never straddles two images).
-static inline bool flat_rows_geometry(const InsarAct& x) {
-  if (x.dtype != INSAR_BF16) return false;
+static inline bool flat_rows_geometry(const InsarAct& x, int dil = 1) {
+  if (x.dtype != INSAR_BF16 || dil < 1 || dil > 15) return false;
   if (x.W < 16 || x.W > FL_BM || (FL_BM % x.W) != 0 || (x.W & (x.W - 1)) != 0) return false;
   if (x.H % (FL_BM / x.W)) return false;
+  if ((FL_BM / x.W) * (x.W + 2 * dil) > FL_GEO1_ROWS) return false;      // the staged rows of a tile must fit the A slot
   return flat_pixels(x) < 0x7fffffffLL;
 }
 extern "C" int insar_conv3x3_flat_rows_ok(const InsarAct* x, int32_t N) {
   return (x && (N % 64) == 0 && (x->c_len % 64) == 0 && flat_rows_geometry(*x)) ? 1 : 0;
+}
+// ... with taps dilated by `dil` (flip bits 8-11; padding = dil: DeepLabV3's layer3 / layer4, DeepLabV3-ChannelAttention.py:87-137
+// through torchvision's replace_stride_with_dilation): the staged rows carry dil columns either side, 256 / W * (W + 2 dil) <= 320
+extern "C" int insar_conv3x3_flat_rows_dil_ok(const InsarAct* x, int32_t N, int32_t dil) {
+  return (x && (N % 64) == 0 && (x->c_len % 64) == 0 && flat_rows_geometry(*x, dil)) ? 1 : 0;
 }
 // Rows of the statistics slab a launch with these flags writes: one per M tile, or — persistent work-groups (flip bit 2)
 // with one N tile — one per work-group.
@@ -630,11 +669,17 @@ static int flat_impl(const InsarAct* x, const InsarAct* y, const void* w, int32_
   a.num_mtiles = flat_mtiles(P);
   hipStream_t s = (hipStream_t)stream;
   const bool wide = (a.N % 128) == 0 && !(flip & 16);      // bit 4: 64-column tiles whatever N (grids of 256 work-groups on the 16^2 level)
+  a.dil = 1;
   if (flip & 8) {       // row tiles (bf16, ping-pong loop)
-    if (!flat_rows_geometry(*x)) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: row tiles need bf16, W a power of two in 16..256 and H a multiple of 256 / W (got %d x %d)", x->H, x->W);
+    a.dil = ((flip >> 8) & 15) ? ((flip >> 8) & 15) : 1;
+    if (!flat_rows_geometry(*x, a.dil)) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: row tiles need bf16, W a power of two in 16..256, H a multiple of 256 / W and 256 / W * (W + 2 * dilation) <= 320 (got %d x %d, dilation %d)", x->H, x->W, a.dil);
     a.num_mtiles = (int)(((long long)x->B * x->H * x->W) / FL_BM);
     a.lw = 0;
     while ((1 << a.lw) < x->W) ++a.lw;
+    if (a.dil > 1) {
+      if (a.by) return wide ? launch_flat<bf16_t, 128, true, true, 2>(a, s) : launch_flat<bf16_t, 64, true, true, 2>(a, s);
+      return wide ? launch_flat<bf16_t, 128, true, false, 2>(a, s) : launch_flat<bf16_t, 64, true, false, 2>(a, s);
+    }
     if (a.by) return wide ? launch_flat<bf16_t, 128, true, true, 1>(a, s) : launch_flat<bf16_t, 64, true, true, 1>(a, s);
     return wide ? launch_flat<bf16_t, 128, true, false, 1>(a, s) : launch_flat<bf16_t, 64, true, false, 1>(a, s);
   }

@@ -224,7 +224,12 @@ class ConvUnit:
         self.out = out if out is not None else Act.alloc(B, self.Ho, self.Wo, self.cout, ctx.dtype, ctx.device)
         if self.out.c_len != self.cout or (self.out.H, self.out.W) != (self.Ho, self.Wo):
             raise _lib.InsarError(f"{name}: output slice does not match the convolution")
-        self.stat_rows = call("insar_igemm_num_mtiles", self.M, self.cout)
+        # 3x3 / stride-1 convs with all nine taps, dense or dilated by <= 4 at 32 x 32 (layer1-4 and the head): the flat kernel's
+        # row tiles (engine.FLAT_ROWS; conv3x3_flat.hip GEO = 1 / 2) wherever the per-tap kernel would not run 256 x 256 tiles
+        self.rows_fwd = self._rows_flags(self.cout)
+        self.rows_bwd = self._rows_flags(self.cin)
+        self.stat_rows = (call("insar_conv3x3_flat_stat_rows", x.ref, self.cout, self.rows_fwd) if self.rows_fwd
+                          else call("insar_igemm_num_mtiles", self.M, self.cout))
         self.stats = ctx.f32(self.stat_rows, 2, self.cout)
         self.stat_rps = 0 if self.stat_rows <= engine.STAT_PREFOLD_ROWS else max(64, -(-self.stat_rows // 64))
         self.fold_rows = self.stat_rows if not self.stat_rps else -(-self.stat_rows // self.stat_rps)
@@ -260,14 +265,31 @@ class ConvUnit:
         w = self.w.fwd() if which == "fwd" else self.w.dgrad()
         return w.data_ptr() + self.tap_ids[0] * self.cout * self.cin * self.ctx.esize
 
+    def _rows_flags(self, N: int) -> int:
+        """flip bits of the flat kernel's row tiles for this unit's convolution to N output columns (forward: cout, input
+        gradient: cin), or 0: the per-tap kernel keeps 1x1 / strided / partially dead convs and its 256 x 256 tiles."""
+        x = self.x
+        if not engine.FLAT_ROWS or self.k != 3 or self.s != 1 or self.centre_only or len(self.taps) != 9 or x.code != _lib.BF16:
+            return 0
+        if self.conv.padding[0] != self.d or not call("insar_conv3x3_flat_rows_dil_ok", x.ref, N, self.d):
+            return 0
+        M = x.B * x.H * x.W
+        if not self.oob and call("insar_igemm_tile_cols_dt", M, N, x.code) == 256:
+            return 0
+        narrow = (N % 128) != 0 or (M // 256) * (N // 128) < 256
+        return 8 | (16 if narrow else 0) | ((self.d << 8) if self.d > 1 else 0)
+
     # ---- forward ------------------------------------------------------------------------------------------
     def forward(self, training: bool) -> None:
         s = _lib.stream_ptr()
         if training and self.M <= 1:
             raise ValueError("Expected more than 1 value per channel when training, got input size "
                              f"torch.Size([{self.x.B}, {self.cout}, {self.Ho}, {self.Wo}])")
-        _igemm(self.x, self.y, self._wptr("fwd"), self.cout, self.Ho, self.Wo, self.s, self.taps, 0,
-               stats=self.stats if training else None, oob=self.oob)
+        if self.rows_fwd:
+            engine._conv3x3_flat(self.x, self.y, self.w.fwd(), 0, self.stats if training else None, geo=self.rows_fwd)
+        else:
+            _igemm(self.x, self.y, self._wptr("fwd"), self.cout, self.Ho, self.Wo, self.s, self.taps, 0,
+                   stats=self.stats if training else None, oob=self.oob)
         if training and self.stat_rps:
             call("insar_colsum_partial", ptr(self.stats), ptr(self.sums), self.stat_rows, 2 * self.cout, self.stat_rps, s)
         bn = self.bn
@@ -332,6 +354,14 @@ class ConvUnit:
         if self.s == 1:
             taps = [(-dy, -dx_) for dy, dx_ in self.taps]
             slab = None
+            if self.rows_bwd and add is None:
+                if bstat_for is not None and engine.BSTAT_FUSE and engine._same_layout(dx, bstat_for.y):
+                    slab = bstat_for.bstat_slab(call("insar_conv3x3_flat_stat_rows", self.dy.ref, self.cin, self.rows_bwd), False)
+                engine._conv3x3_flat(self.dy, dx, self.w.dgrad(), 1, slab[0] if slab else None, bstat=slab[1] if slab else None,
+                                     geo=self.rows_bwd)
+                if slab:
+                    bstat_for.bred_ready = True
+                return
             if add is None and bstat_for is not None:
                 slab = engine._igemm_bstat_slab(bstat_for, False, self.x.B * H * W, self.cin, H * W, dx)
             _igemm(self.dy, dx, self._wptr("dgrad"), self.cin, H, W, 1, taps, 0, oob=self.oob, add=add,

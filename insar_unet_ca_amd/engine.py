@@ -421,7 +421,7 @@ def _conv3x3_flat(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[to
         flops = 2.0 * x.B * x.H * x.W * y.c_len * x.c_len * 9
         tag = "conv3x3_flat_kernel<%s, %d>%s%s" % ("float" if x.code == _lib.F32 else "bf16_t",
                                                    128 if (y.c_len % 128 == 0 and not (geo & 16)) else 64,
-                                                   " row tiles" if geo else "", " +bstat" if bstat is not None else "")
+                                                   (" row tiles" + (" dilated" if geo >> 8 else "")) if geo else "", " +bstat" if bstat is not None else "")
         PROFILER.run(tag, flops, fn)
         return
     fn()

@@ -230,6 +230,48 @@ def test_conv3x3_flat_against_float64(dev, dtype, cin, cout, shape):
     assert _halo_abs(dxa) == 0.0
 
 
+@pytest.mark.parametrize("cin,cout,shape,dil,narrow", [
+    (64, 128, (2, 64, 32, 32), 2, False),      # DeepLabV3 layer3 / layer4 geometry: 8 rows per tile, 36 staged columns
+    (128, 64, (2, 128, 32, 32), 4, True),      # dilation 4: 40 staged columns, 320 staged rows (the A slot exactly), 64-column tiles
+    (64, 64, (1, 64, 16, 64), 2, False),       # 4 rows per tile, dilation 2
+    (64, 128, (3, 64, 8, 32), 3, False),       # an odd dilation, one tile per image
+])
+def test_conv3x3_flat_dilated_row_tiles_against_float64(dev, cin, cout, shape, dil, narrow):
+    """Row tiles of a dilated 3x3 convolution (padding = dilation; flip bits 8-11): taps that reach beyond the one-pixel halo
+    of the activation buffer read zeros. Forward with BatchNorm partial sums and input gradient against float64 and against
+    the per-tap kernel's out-of-bounds variant (same operands; different accumulation order: output rounding apart)."""
+    from insar_unet_ca_amd import _lib, engine
+    from insar_unet_ca_amd._lib import call, ptr
+    dtype = torch.bfloat16
+    ctx = engine.Ctx(dev, dtype)
+    b, _, h, w = shape
+    xa = _act_from(cf.make_input(shape), dtype, dev)
+    assert call("insar_conv3x3_flat_rows_dil_ok", xa.ref, cout, dil) == 1
+    assert call("insar_conv3x3_flat_rows_dil_ok", xa.ref, cout, 15) == 0            # 256 / W * (W + 30) > 320
+    ya, yb = (engine.Act.alloc(b, h, w, cout, dtype, dev) for _ in range(2))
+    p = torch.nn.Parameter(cf.fill_tensor("weight", (cout, cin, 3, 3), 11).to(dev))
+    gw = engine.GemmWeight(ctx, p, "conv3")
+    flags = 8 | 2 | (16 if narrow else 0) | (dil << 8)
+    stats = torch.zeros(call("insar_conv3x3_flat_stat_rows", xa.ref, cout, flags), 2, cout, device=dev)
+    call("insar_conv3x3_flat", xa.ref, ya.ref, ptr(gw.fwd()), flags, ptr(stats), _lib.stream_ptr())
+    xr = xa.nchw().cpu().double()
+    wr = gw.fwd().float().cpu().reshape(3, 3, cout, cin).permute(2, 3, 0, 1).double()
+    ref = F.conv2d(xr, wr, padding=dil, dilation=dil)
+    assert max_rel(ya.nchw(), ref) <= 6e-3
+    assert _halo_abs(ya) == 0.0
+    got = ya.nchw().double().cpu()
+    assert max_rel(stats.sum(0)[0], got.sum((0, 2, 3))) <= 1e-4
+    assert max_rel(stats.sum(0)[1], (got ** 2).sum((0, 2, 3))) <= 1e-4
+    taps = [(ky * dil - dil, kx * dil - dil) for ky in range(3) for kx in range(3)]
+    engine._igemm(xa, yb, gw.fwd(), cout, h, w, 1, taps, 0, oob=True)
+    assert max_rel(ya.nchw(), yb.nchw().double().cpu()) <= 1.2e-2
+    ga = _act_from(cf.make_grad((b, cout, h, w)), dtype, dev)
+    dxa = engine.Act.alloc(b, h, w, cin, dtype, dev)
+    call("insar_conv3x3_flat", ga.ref, dxa.ref, ptr(gw.dgrad()), flags | 1, 0, _lib.stream_ptr())
+    assert max_rel(dxa.nchw(), F.conv_transpose2d(ga.nchw().cpu().double(), wr, padding=dil, dilation=dil)) <= 6e-3
+    assert _halo_abs(dxa) == 0.0
+
+
 @pytest.mark.parametrize("cin,cout,shape,narrow", [
     (128, 128, (2, 128, 32, 32), False),     # 8 image rows per tile, one N tile
     (256, 64, (4, 256, 16, 16), False),      # a tile = one whole 16 x 16 image, four K slabs per tap
