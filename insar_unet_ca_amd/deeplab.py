@@ -402,7 +402,7 @@ class ConvUnit:
         tm, tn = engine._wgrad_tiles(self.cin, self.cout, ctx.code)
         tiles = nt * (self.cin // tm) * (self.cout // tn)
         alone = ctx.side is None or (engine.PROFILER is not None and engine.PROFILER.alone)
-        fill = 1.0 if alone else engine._side_fill(ctx, engine.WGRAD_FILL_T)
+        fill = 1.0 if alone else engine._side_fill(ctx, engine.WGRAD_FILL_DL)
         nsplit = _wgrad_nsplit(tiles, mpad // engine.WG_BKP, nt * self.cout * self.cin, tm, tn, ctx.esize, fill=fill)
         part = ctx.wgrad_part(nsplit * nt * self.cout * self.cin)
         d = InsarWgrad()

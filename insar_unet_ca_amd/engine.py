@@ -331,6 +331,7 @@ COEF_FUSE = os.environ.get("INSAR_COEF_FUSE", "1") != "0"        # diagnostic: 0
 COEF_SIMPLE = os.environ.get("INSAR_COEF_SIMPLE", "1") != "0"    # units without an SE gate: the channel-parallel one-launch kernel (0 = the ticket kernel)
 OUTC_WGRAD_FUSE = os.environ.get("INSAR_OUTC_WGRAD_FUSE", "1") != "0"   # diagnostic: 0 = outc's weight gradient in its own pass over y
 WGRAD_FILL_T = float(os.environ.get("INSAR_WGRAD_FILL_T", "0.7"))   # the same for the transposed convs' per-tap weight gradient
+WGRAD_FILL_DL = float(os.environ.get("INSAR_WGRAD_FILL_DL", "0.5"))  # ... and for DeepLabV3-CA's per-tap weight gradients (1x1 / dilated / strided convs: most of its side stream; config 5 same-box 0.5 9.32, 0.6 9.42, 0.7 9.51, 0.85 9.60 ms/step)
 WGRAD_FILL_ALONE = float(os.environ.get("INSAR_WGRAD_FILL_ALONE", "1.0"))   # ... and when it has the GPU to itself
 WGRAD_FILL = float(os.environ.get("INSAR_WGRAD_FILL", "0.6"))     # share of the work-group slots a side-stream weight gradient aims at (0.5 until the row tiles made the dgrad chain faster: re-swept, 0.55-0.65 with 0.7 for the transposed convs is 0.09 ms better, profiles/r03_row_tiles.txt)
 WGRAD_ROWS = os.environ.get("INSAR_WGRAD_ROWS", "1") != "0"      # diagnostic: 0 = per-tap weight-gradient kernel everywhere
