@@ -129,10 +129,12 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
   float cs1[CHc], cs2[CHc];
 #pragma unroll
   for (int j = 0; j < CHc; ++j) { cs1[j] = 0.f; cs2[j] = 0.f; }
-  float4* carry = (float4*)(smem + Cfg::MAIN + Cfg::ROWINFO + Cfg::STATB) + threadIdx.x * (2 * CHc / 4);   // LDS_CARRY only
+  // LDS_CARRY only: 16-byte slot q of thread t at [q][t] (consecutive lanes, consecutive slots: no bank conflict)
+  float4* carry = (float4*)(smem + Cfg::MAIN + Cfg::ROWINFO + Cfg::STATB) + threadIdx.x;
+  constexpr int CST = FL_THREADS;      // stride between a thread's slots
   if constexpr (Cfg::LDS_CARRY) {
 #pragma unroll
-    for (int j = 0; j < 2 * CHc / 4; ++j) carry[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < 2 * CHc / 4; ++j) carry[j * CST] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #ifdef INSAR_STAMPS
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // wave-uniform (scalar registers)
@@ -491,10 +493,10 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
       // same sums in the same order as the register carry: slot j of the thread += this tile's sum
 #pragma unroll
       for (int q = 0; q < CH / 4; ++q) {
-        float4 c1v = carry[q], c2v = carry[CH / 4 + q];
+        float4 c1v = carry[q * CST], c2v = carry[(CH / 4 + q) * CST];
         c1v.x += s1[4 * q]; c1v.y += s1[4 * q + 1]; c1v.z += s1[4 * q + 2]; c1v.w += s1[4 * q + 3];
         c2v.x += s2[4 * q]; c2v.y += s2[4 * q + 1]; c2v.z += s2[4 * q + 2]; c2v.w += s2[4 * q + 3];
-        carry[q] = c1v; carry[CH / 4 + q] = c2v;
+        carry[q * CST] = c1v; carry[(CH / 4 + q) * CST] = c2v;
       }
     } else {
 #pragma unroll
@@ -535,9 +537,12 @@ __global__ __launch_bounds__(FL_THREADS, 2) void conv3x3_flat_kernel(FlatArgs a)
     constexpr int CPR = BN * ES / 16;
     constexpr int CH = CHc;
     if constexpr (Cfg::LDS_CARRY) {
-      const float* cf = (const float*)carry;
 #pragma unroll
-      for (int j = 0; j < CH; ++j) { cs1[j] = cf[j]; cs2[j] = cf[CH + j]; }
+      for (int q = 0; q < CH / 4; ++q) {
+        const float4 c1v = carry[q * CST], c2v = carry[(CH / 4 + q) * CST];
+        cs1[4 * q] = c1v.x; cs1[4 * q + 1] = c1v.y; cs1[4 * q + 2] = c1v.z; cs1[4 * q + 3] = c1v.w;
+        cs2[4 * q] = c2v.x; cs2[4 * q + 1] = c2v.y; cs2[4 * q + 2] = c2v.z; cs2[4 * q + 3] = c2v.w;
+      }
     }
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
