@@ -355,7 +355,9 @@ class ConvUnit:
             taps = [(-dy, -dx_) for dy, dx_ in self.taps]
             slab = None
             if self.rows_bwd and add is None:
-                if bstat_for is not None and engine.BSTAT_FUSE and engine._same_layout(dx, bstat_for.y):
+                # (the dilated 128-column instantiation with the sums in its epilogue spills: 130 us against 68 + a 20 us reduce pass)
+                heavy = (self.rows_bwd >> 8) and not (self.rows_bwd & 16)
+                if bstat_for is not None and engine.BSTAT_FUSE and not heavy and engine._same_layout(dx, bstat_for.y):
                     slab = bstat_for.bstat_slab(call("insar_conv3x3_flat_stat_rows", self.dy.ref, self.cin, self.rows_bwd), False)
                 engine._conv3x3_flat(self.dy, dx, self.w.dgrad(), 1, slab[0] if slab else None, bstat=slab[1] if slab else None,
                                      geo=self.rows_bwd)
