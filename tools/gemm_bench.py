@@ -102,13 +102,21 @@ def main():
                 for narrow in (0, 16):
                     fl = 8 | 2 | narrow
                     st3 = torch.zeros(call("insar_conv3x3_flat_stat_rows", x.ref, cout, fl), 2, cout, device=dev)
-                    rr = {"igemm": [], "rows": []}
+                    rr = {"igemm": [], "rows": [], "flat": []}
+                    flat_ok = call("insar_conv3x3_flat_ok", x.ref, cout) and call("insar_conv3x3_flat_ok", g.ref, cin) and not narrow
+                    if flat_ok:
+                        st4 = torch.zeros(call("insar_conv3x3_flat_stat_rows", x.ref, cout, 2 | 4), 2, cout, device=dev)
                     for r in range(4):
+                        if flat_ok:      # the flat pixel-space geometry as the step runs it: ping-pong, persistent
+                            rr["flat"].append((run(lambda: call("insar_conv3x3_flat", x.ref, y.ref, ptr(wf), 2 | 4, ptr(st4), _lib.stream_ptr())),
+                                               run(lambda: call("insar_conv3x3_flat", g.ref, dx.ref, ptr(wd), 2 | 4 | 1, 0, _lib.stream_ptr()))))
                         rr["igemm"].append((run(lambda: engine._igemm(x, y, wf, cout, hw, hw, 1, engine._TAPS3, 0, stats=stats)),
                                             run(lambda: engine._igemm(g, dx, wd, cin, hw, hw, 1, engine._TAPS3_DGRAD, 0))))
                         rr["rows"].append((run(lambda: call("insar_conv3x3_flat", x.ref, y.ref, ptr(wf), fl, ptr(st3), _lib.stream_ptr())),
                                            run(lambda: call("insar_conv3x3_flat", g.ref, dx.ref, ptr(wd), fl | 1, 0, _lib.stream_ptr()))))
-                    for k in ("igemm", "rows"):
+                    for k in ("igemm", "rows", "flat"):
+                        if not rr[k]:
+                            continue
                         f = sorted(v[0] for v in rr[k]); d = sorted(v[1] for v in rr[k])
                         res.append(f"\n   {k:5s} narrow={narrow >> 4}: fwd min {f[0]:6.1f} med {f[len(f)//2]:6.1f} us ({flops/f[0]/1e6:5.0f} TF)  dgrad min {d[0]:6.1f} med {d[len(d)//2]:6.1f} us ({flops/d[0]/1e6:5.0f} TF)")
         if "flat" in what:
