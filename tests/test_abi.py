@@ -96,3 +96,28 @@ def test_tile_selection_queries_without_a_gpu():
     assert mt == (16 * 258 * 258 + 253) // 254
     assert call("insar_conv3x3_flat_stat_rows", big, 64, 0) == mt and call("insar_conv3x3_flat_stat_rows", big, 64, 4) == 256
     assert call("insar_conv3x3_flat_stat_rows", small, 64, 4) == call("insar_conv3x3_flat_num_mtiles", small) < 256
+
+
+def test_row_tile_geometry_queries():
+    """Applicability of the flat kernel's row tiles (flip bit 3) and the rows of their statistics slab: host-only queries.
+    A tile is 256 real pixels = 256 / W whole image rows of one image, staged with d halo columns either side."""
+    lib = _lib.load()
+    call = lambda name, *a: getattr(lib, name)(*a)
+    BF16, F32 = _lib.BF16, _lib.F32
+    act = lambda b, h, w, c, dt: ctypes.byref(_lib.InsarAct(0, b, h, w, c, 0, c, dt, 0))
+    ok = lambda b, h, w, c, n, dt=BF16: call("insar_conv3x3_flat_rows_ok", act(b, h, w, c, dt), n)
+    # every level of the U-Net at 256 x 256 tiles, and the reference's other tile sizes that keep W a power of two
+    assert all(ok(16, s, s, 64, 64) == 1 for s in (16, 32, 64, 128, 256))
+    assert ok(1, 16, 16, 1024, 1024) == 1 and ok(3, 8, 32, 64, 128) == 1 and ok(2, 2, 128, 64, 64) == 1
+    assert ok(16, 256, 256, 64, 64, F32) == 0                     # bf16 only
+    assert ok(16, 8, 8, 64, 64) == 0 and ok(16, 512, 512, 64, 64) == 0 and ok(16, 48, 48, 64, 64) == 0    # W < 16, > 256, not 2^k
+    assert ok(2, 3, 128, 64, 64) == 0 and ok(2, 12, 32, 64, 64) == 0   # H not a multiple of 256 / W: a tile would straddle images
+    assert ok(16, 32, 32, 96, 64) == 0 and ok(16, 32, 32, 64, 96) == 0  # channels in 64s
+    dil = lambda h, w, d: call("insar_conv3x3_flat_rows_dil_ok", act(16, h, w, 256, BF16), 256, d)
+    assert dil(32, 32, 1) == 1 and dil(32, 32, 2) == 1 and dil(32, 32, 4) == 1 and dil(32, 32, 5) == 0   # 8 * (32 + 2 d) <= 320
+    assert dil(16, 16, 2) == 1 and dil(16, 16, 3) == 0 and dil(64, 64, 8) == 1 and dil(64, 64, 9) == 0
+    assert dil(32, 32, 0) == 0 and dil(32, 32, 16) == 0
+    # statistics slab: one row per tile, whatever the other bits say
+    x = act(16, 32, 32, 512, BF16)
+    for flags in (8, 8 | 16, 8 | 4, 8 | 2 | (2 << 8)):
+        assert call("insar_conv3x3_flat_stat_rows", x, 512, flags) == 16 * 32 * 32 // 256
