@@ -35,6 +35,13 @@ __global__ void pack_scalar_kernel(const float* __restrict__ src, ActView dst, i
     int64_t rem = p - (int64_t)n * HW;
     int h = (int)(rem / dst.W), w = (int)(rem - (int64_t)h * dst.W);
     T* out = (T*)(dst.base + dst.elem_offset(n, h, w) * (int64_t)sizeof(T));
+    if constexpr (sizeof(T) == 2) {
+      if (Csrc == 2 && dst.C == 2) {      // the two-channel InSAR tile: both planes' values in one 4-byte store
+        const float v0 = src[((int64_t)n * 2 + 0) * HW + rem], v1 = src[((int64_t)n * 2 + 1) * HW + rem];
+        *(uint32_t*)out = pack2_bf16(v0, v1);
+        continue;
+      }
+    }
     for (int c = 0; c < Csrc; ++c) {
       float v = src[((int64_t)n * Csrc + c) * HW + rem];
       if constexpr (sizeof(T) == 2) ((uint16_t*)out)[c] = f32_to_bf16(v);
