@@ -419,7 +419,8 @@ def test_weight_relayout_single_and_batched(dev, dtype):
     paired kernel (both forms from one read) give exactly the permutations of the fp32 master."""
     from insar_unet_ca_amd import engine
     ctx = engine.Ctx(dev, dtype)
-    shapes = [("conv3", (128, 64, 3, 3)), ("conv3", (64, 192, 3, 3)), ("convT", (128, 64, 2, 2)), ("convT", (64, 64, 2, 2))]
+    shapes = [("conv3", (128, 64, 3, 3)), ("conv3", (64, 192, 3, 3)), ("convT", (128, 64, 2, 2)), ("convT", (64, 64, 2, 2)),
+              ("conv3", (96, 40, 3, 3)), ("conv3", (2, 256, 1, 1)), ("conv3", (33, 7, 3, 3)), ("conv3", (256, 128, 1, 1))]     # ragged 64 x 64 tiles, odd extents
     params = [torch.nn.Parameter(cf.fill_tensor("weight", shp, 3 + i).to(dev)) for i, (_, shp) in enumerate(shapes)]
     single = [engine.GemmWeight(ctx, p, kind) for p, (kind, _) in zip(params, shapes)]
     batched = [engine.GemmWeight(ctx, p, kind) for p, (kind, _) in zip(params, shapes)]
@@ -427,8 +428,8 @@ def test_weight_relayout_single_and_batched(dev, dtype):
     for (kind, shp), p, a, b in zip(shapes, params, single, batched):
         w = p.detach().to(dtype)
         if kind == "conv3":     # (Co,Ci,3,3) -> [tap][co][ci] and [tap][ci][co]
-            fwd = w.permute(2, 3, 0, 1).reshape(9, shp[0], shp[1])
-            dgr = w.permute(2, 3, 1, 0).reshape(9, shp[1], shp[0])
+            fwd = w.permute(2, 3, 0, 1).reshape(shp[2] * shp[3], shp[0], shp[1])
+            dgr = w.permute(2, 3, 1, 0).reshape(shp[2] * shp[3], shp[1], shp[0])
         else:                   # (Ci,Co,2,2) -> [tap][co][ci] and [tap][ci][co]
             fwd = w.permute(2, 3, 1, 0).reshape(4, shp[1], shp[0])
             dgr = w.permute(2, 3, 0, 1).reshape(4, shp[0], shp[1])
