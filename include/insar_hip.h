@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define INSAR_ABI_VERSION 3
+#define INSAR_ABI_VERSION 4
 
 enum { INSAR_F32 = 0, INSAR_BF16 = 1 };
 
@@ -120,6 +120,9 @@ typedef struct InsarIgemm {
   int32_t _pad;
   const void* add;     /* nullable, mode 0: a tensor with y's buffer layout (same C, c_off, dtype), added to the result */
   InsarBstat bstat;    /* mode 0, dense output, with stats: BatchNorm-backward sums instead of (sum, sum of squares) */
+  const void* gate;    /* nullable, mode 0, no stats (ABI 4): a tensor with y's buffer layout; the result (after bias / add) is stored as
+                        * zero where it is <= 0 — the ReLU mask of a residual block's input applied to the block's input gradient by
+                        * the GEMM that writes it (torchvision Bottleneck `out = relu(out + identity)`, DeepLabV3-ChannelAttention.py:95) */
 } InsarIgemm;
 /* flags. OOB_ZERO: taps may leave the padded input and read zeros there (dilated 3x3 convolutions of DeepLabV3's
  * layer3 / layer4 / ASPP, torchvision resnet.py / deeplabv3.py; the 1-pixel halo covers only |dy|,|dx| <= 1). */

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INSAR_HIP_LIB") or os.path.join(_HERE, "libinsar_hip.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 IGEMM_OOB_ZERO = 1
 IGEMM_PINGPONG = 2
 
@@ -35,7 +35,7 @@ class InsarIgemm(C.Structure):
                 ("stats", C.c_void_p), ("N", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
                 ("stride", C.c_int32), ("ntaps", C.c_int32), ("mode", C.c_int32),
                 ("dy", C.c_int8 * 12), ("dx", C.c_int8 * 12), ("flags", C.c_int32), ("out_stride", C.c_int32),
-                ("out_oy", C.c_int32), ("out_ox", C.c_int32), ("_pad", C.c_int32), ("add", C.c_void_p), ("bstat", InsarBstat)]
+                ("out_oy", C.c_int32), ("out_ox", C.c_int32), ("_pad", C.c_int32), ("add", C.c_void_p), ("bstat", InsarBstat), ("gate", C.c_void_p)]
 
 
 class InsarWgrad(C.Structure):

@@ -39,6 +39,7 @@ struct IgemmArgs {
   signed char tdy[12], tdx[12];   // the taps themselves (OOB variant: per-row bounds test)
   int out_stride, out_oy, out_ox;   // mode 0: row (ho, wo) is stored at output pixel (ho*out_stride + out_oy, wo*out_stride + out_ox)
   const char* add; // nullable: tensor with y's layout added to the result in the epilogue (residual / gradient sum)
+  const char* gate; // nullable: tensor with y's layout; the result is stored as zero where it is <= 0 (ReLU mask of a residual block's input)
   const char* by; const float* bscale; const float* bshift;   // BatchNorm-backward sums in the stats slab (InsarBstat)
 };
 
@@ -460,6 +461,12 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
 #pragma unroll
         for (int j = 0; j < CH; ++j) f[j] += g[j];
       }
+      if (a.gate) {
+        float q[CH];
+        Chunk<T>::unpack(*(const uint4*)(a.gate + (ro + col_off) * ES), q);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) f[j] = q[j] > 0.f ? f[j] : 0.f;
+      }
       *(uint4*)(a.y + (ro + col_off) * ES) = Chunk<T>::pack(f);
     }
   }
@@ -595,6 +602,8 @@ extern "C" int insar_igemm(const InsarIgemm* d, void* stream) {
   if (oob && d->x.H + 2 > 0x3fff) INSAR_FAIL(INSAR_E_SHAPE, "insar_igemm: input too tall for the out-of-bounds variant");
   if (d->add && d->mode != 0) INSAR_FAIL(INSAR_E_ARG, "insar_igemm: `add` needs mode 0");
   if (d->add && !insar_aligned16(d->add)) INSAR_FAIL(INSAR_E_ALIGN, "insar_igemm: add not 16-byte aligned");
+  if (d->gate && (d->mode != 0 || d->stats)) INSAR_FAIL(INSAR_E_ARG, "insar_igemm: `gate` needs mode 0 and no stats slab");
+  if (d->gate && !insar_aligned16(d->gate)) INSAR_FAIL(INSAR_E_ALIGN, "insar_igemm: gate not 16-byte aligned");
   // every tap of every row must stay inside the padded input (unless out-of-bounds taps read zeros)
   for (int t = 0; t < d->ntaps && !oob; ++t) {
     const int ymin = d->dy[t], ymax = (d->Ho - 1) * d->stride + d->dy[t];
@@ -614,7 +623,7 @@ extern "C" int insar_igemm(const InsarIgemm* d, void* stream) {
     a.tapoff[t] = t < d->ntaps ? (d->dy[t] * (d->x.W + 2) + d->dx[t]) * d->x.C : 0;
     a.tdy[t] = t < d->ntaps ? d->dy[t] : 0; a.tdx[t] = t < d->ntaps ? d->dx[t] : 0;
   }
-  a.add = (const char*)d->add;
+  a.add = (const char*)d->add; a.gate = (const char*)d->gate;
   a.by = (const char*)d->bstat.y; a.bscale = d->bstat.scale; a.bshift = d->bstat.shift;
   if (a.by) {
     if (d->mode != 0 || os != 1 || !d->stats || !a.bscale || !a.bshift || d->bias || d->add)

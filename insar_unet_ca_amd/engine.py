@@ -358,9 +358,10 @@ _TAPS2 = [(a, b) for a in range(2) for b in range(2)]
 
 def _igemm(x: Act, y: Act, w, N: int, Ho: int, Wo: int, stride: int, taps, mode: int,
            bias: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, oob: bool = False,
-           add: Optional[Act] = None, out_stride: int = 1, out_off=(0, 0), bstat=None) -> None:
+           add: Optional[Act] = None, out_stride: int = 1, out_off=(0, 0), bstat=None, gate: Optional[Act] = None) -> None:
     """w: tensor, or a raw device pointer (a tap slice of a GEMM-layout weight). bstat = (y Act, scale, shift): the stats
-    slab receives the BatchNorm-backward sums of the unit that consumes this GEMM's output (InsarBstat)."""
+    slab receives the BatchNorm-backward sums of the unit that consumes this GEMM's output (InsarBstat). gate: the result is
+    stored as zero where this tensor (the output's layout) is <= 0."""
     d = InsarIgemm()
     if bstat is not None:
         d.bstat.y, d.bstat.scale, d.bstat.shift = bstat[0].buf.data_ptr(), ptr(bstat[1]), ptr(bstat[2])
@@ -373,6 +374,10 @@ def _igemm(x: Act, y: Act, w, N: int, Ho: int, Wo: int, stride: int, taps, mode:
         if add.C != y.C or add.c_off != y.c_off or add.buf.dtype != y.buf.dtype or add.buf.shape != y.buf.shape:
             raise _lib.InsarError("igemm: `add` must have the output's buffer layout")
         d.add = add.buf.data_ptr()
+    if gate is not None:
+        if gate.C != y.C or gate.c_off != y.c_off or gate.buf.dtype != y.buf.dtype or gate.buf.shape != y.buf.shape:
+            raise _lib.InsarError("igemm: `gate` must have the output's buffer layout")
+        d.gate = gate.buf.data_ptr()
     for i, (dy, dx) in enumerate(taps):
         d.dy[i], d.dx[i] = dy, dx
     if PROFILER is not None:

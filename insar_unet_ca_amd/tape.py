@@ -17,6 +17,7 @@ Python threads of one process should run with INSAR_TAPE=0.
 on ROCm 7.2 — DESIGN.md — so the tape keeps eager launches and removes the host work around them.)"""
 from __future__ import annotations
 
+import sys
 import ctypes as C
 import os
 from typing import Callable, Dict, List, Optional
@@ -133,7 +134,8 @@ class PlanTape:
         # module-level switches the launch code reads at call time (tests flip them with monkeypatch): part of the key too
         flags = (engine.BSTAT_FUSE, engine.BSTAT_C64, engine.COEF_SIMPLE, engine.COEF_FUSE, engine.SPLIT_COEF, engine.POOL_FUSE,
                  engine.OUTC_FUSE, engine.OUTC_WGRAD_FUSE, engine.PREP_SIDE, engine.WGRAD_LATE, engine.WGRAD_ROWS, engine.FLAT_PP,
-                 engine.FLAT_PERSIST, engine.FLAT_ROWS, engine.IGEMM_PP, engine.WGRAD_FILL, engine.WGRAD_FILL_T, engine.WGRAD_FILL_DL, engine.WGRAD_GRID_CAP)
+                 engine.FLAT_PERSIST, engine.FLAT_ROWS, engine.IGEMM_PP, engine.WGRAD_FILL, engine.WGRAD_FILL_T, engine.WGRAD_FILL_DL, engine.WGRAD_GRID_CAP,
+                 getattr(sys.modules.get(__package__ + ".deeplab"), "GATE_FUSE", None))
         return (which, self.sink.active if which == "b" else 0, hash(bn), hash(flags))
 
     def _tape_allowed(self, training: bool, extra_ok: bool = True) -> bool:

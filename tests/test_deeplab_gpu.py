@@ -144,6 +144,32 @@ def test_deeplab_train_forward_backward_against_oracle(dev, shape):
     assert hip_err["model.classifier.4.weight"] <= 1e-3 and hip_err["model.classifier.4.bias"] <= 1e-3
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_residual_relu_gate_in_the_gemm_epilogue_is_bitwise(dev, dtype, monkeypatch):
+    """The ReLU mask of a residual block's output applied by the GEMM that writes the block's incoming gradient
+    (InsarIgemm.gate) against the pass of its own (insar_relu_gate_bwd): every parameter gradient bit for bit."""
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd import deeplab, tape
+    monkeypatch.setattr(tape, "MODE", "0")
+    x, y = _input((2, 1, 64, 64), 11)
+    grads = []
+    for fuse in (True, False):
+        monkeypatch.setattr(deeplab, "GATE_FUSE", fuse)
+        net, _sd = _make(dev, 33, dtype=dtype, p_drop=0.0)
+        net.train()
+        calls = []
+        orig = deeplab.call
+        monkeypatch.setattr(deeplab, "call", lambda name, *a: (calls.append(name), orig(name, *a))[1])
+        loss = iu.CrossEntropyLoss(ignore_index=255)(net(x.to(dev)), y.to(dev))
+        loss.backward()
+        monkeypatch.setattr(deeplab, "call", orig)
+        n_gate = calls.count("insar_relu_gate_bwd")
+        assert n_gate == (16 if not fuse else 2), n_gate      # fused: only layer4's last block (the head writes its gradient) and layer1's last (a strided consumer)
+        grads.append({k: p.grad.detach().clone() for k, p in net.named_parameters()})
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
+
+
 def test_deeplab_dropout_under_a_given_mask_and_adam_steps(dev):
     """Training mode with Dropout(0.5): the HIP path draws its own mask (torch's Philox stream cannot be reproduced); the
     oracle is given that mask. Then three Adam steps on both sides with externally supplied masks: the loss curves agree."""
