@@ -441,15 +441,7 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
     if (ro >= 0) {
       float f[CH];
       Chunk<T>::unpack(*(const uint4*)(tile + row * Cfg::PITCH + cc * 16), f);
-      if constexpr (BS) {
-        float yy[CH];
-        Chunk<T>::unpack(yv[i], yy);
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-          const float m = fmaf(yy[j], bsc[j], bsh[j]) > 0.f ? f[j] : 0.f;
-          s1[j] += m; s2[j] = fmaf(m, yy[j], s2[j]);
-        }
-      } else {
+      if constexpr (!BS) {
 #pragma unroll
         for (int j = 0; j < CH; ++j) { s1[j] += f[j]; s2[j] = fmaf(f[j], f[j], s2[j]); }
       }
@@ -467,7 +459,20 @@ __global__ __launch_bounds__(2 * BM, (BN >= 256 ? 1 : 2)) void igemm_kernel(Igem
 #pragma unroll
         for (int j = 0; j < CH; ++j) f[j] = q[j] > 0.f ? f[j] : 0.f;
       }
-      *(uint4*)(a.y + (ro + col_off) * ES) = Chunk<T>::pack(f);
+      const uint4 pk = Chunk<T>::pack(f);
+      *(uint4*)(a.y + (ro + col_off) * ES) = pk;
+      if constexpr (BS) {
+        // BatchNorm-backward sums of the consumer over the values AS STORED (after add / gate, rounded to T: what a reduce
+        // pass over the output would read; without add / gate that is the tile value itself, bit for bit)
+        float yy[CH], fr[CH];
+        Chunk<T>::unpack(yv[i], yy);
+        Chunk<T>::unpack(pk, fr);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const float m = fmaf(yy[j], bsc[j], bsh[j]) > 0.f ? fr[j] : 0.f;
+          s1[j] += m; s2[j] = fmaf(m, yy[j], s2[j]);
+        }
+      }
     }
   }
   IG_STAMP(4);          // stores (+ sums)
@@ -602,7 +607,7 @@ extern "C" int insar_igemm(const InsarIgemm* d, void* stream) {
   if (oob && d->x.H + 2 > 0x3fff) INSAR_FAIL(INSAR_E_SHAPE, "insar_igemm: input too tall for the out-of-bounds variant");
   if (d->add && d->mode != 0) INSAR_FAIL(INSAR_E_ARG, "insar_igemm: `add` needs mode 0");
   if (d->add && !insar_aligned16(d->add)) INSAR_FAIL(INSAR_E_ALIGN, "insar_igemm: add not 16-byte aligned");
-  if (d->gate && (d->mode != 0 || d->stats)) INSAR_FAIL(INSAR_E_ARG, "insar_igemm: `gate` needs mode 0 and no stats slab");
+  if (d->gate && (d->mode != 0 || (d->stats && !d->bstat.y))) INSAR_FAIL(INSAR_E_ARG, "insar_igemm: `gate` needs mode 0 and no forward statistics (BatchNorm-backward sums are taken over the gated values)");
   if (d->gate && !insar_aligned16(d->gate)) INSAR_FAIL(INSAR_E_ALIGN, "insar_igemm: gate not 16-byte aligned");
   // every tap of every row must stay inside the padded input (unless out-of-bounds taps read zeros)
   for (int t = 0; t < d->ntaps && !oob; ++t) {
@@ -626,8 +631,8 @@ extern "C" int insar_igemm(const InsarIgemm* d, void* stream) {
   a.add = (const char*)d->add; a.gate = (const char*)d->gate;
   a.by = (const char*)d->bstat.y; a.bscale = d->bstat.scale; a.bshift = d->bstat.shift;
   if (a.by) {
-    if (d->mode != 0 || os != 1 || !d->stats || !a.bscale || !a.bshift || d->bias || d->add)
-      INSAR_FAIL(INSAR_E_ARG, "insar_igemm: bstat needs mode 0, a dense output, a stats slab, scale / shift, no bias, no add");
+    if (d->mode != 0 || os != 1 || !d->stats || !a.bscale || !a.bshift || d->bias)
+      INSAR_FAIL(INSAR_E_ARG, "insar_igemm: bstat needs mode 0, a dense output, a stats slab, scale / shift, no bias");
     if (!insar_aligned16(a.by)) INSAR_FAIL(INSAR_E_ALIGN, "insar_igemm: bstat.y not 16-byte aligned");
   }
   a.out_stride = os; a.out_oy = d->mode == 0 ? d->out_oy : 0; a.out_ox = d->mode == 0 ? d->out_ox : 0;

@@ -29,6 +29,7 @@ from .engine import Act, Ctx, GemmWeight, GradSink, OutConvPlan, WeightSet, _ige
 from .modules import ChannelAttentionModule, _PlanCache, _UNetFn, _require_device, _resolve_dtype
 
 ASPP_RATES = (12, 24, 36)
+GATE_STATS = os.environ.get("INSAR_GATE_STATS", "1") != "0"    # diagnostic: 0 = the last unit of a residual block reduces its (gated) incoming gradient in a pass of its own
 GATE_FUSE = os.environ.get("INSAR_GATE_FUSE", "1") != "0"      # diagnostic: 0 = every residual block gates its incoming gradient in a pass of its own
 
 
@@ -250,14 +251,23 @@ class ConvUnit:
         # BatchNorm-backward sums written by the epilogue of the GEMM that produces this unit's incoming gradient
         # (engine.ConvBN.bstat_slab, InsarBstat)
         self.bred, self.bred_rows, self.bred_ready = None, 0, False
+        self.bred_plain, self._mask_off = False, None
 
-    def bstat_slab(self, rows_total: int, per_image: bool):
+    def bstat_slab(self, rows_total: int, per_image: bool, plain: bool = False):
+        """(slab, (y, scale, shift)) for a GEMM that writes this unit's incoming gradient and takes its BatchNorm-backward
+        sums in its epilogue. plain: sums without the unit's own ReLU mask (a residual block's last unit, whose gradient
+        arrives already gated by the block's ReLU: scale 0 / shift 1 make the mask all-ones)."""
         B = self.x.B
-        if not self.relu or (per_image and rows_total % B):
+        if (not self.relu and not plain) or (per_image and rows_total % B):
             return None
         rows = -(-rows_total // B)
         if self.bred is None or self.bred_rows != rows:
             self.bred, self.bred_rows = self.ctx.f32(B * rows, 2, self.cout), rows
+        self.bred_plain = plain
+        if plain:
+            if self._mask_off is None:
+                self._mask_off = (torch.zeros(self.cout, device=self.ctx.device), torch.ones(self.cout, device=self.ctx.device))
+            return self.bred, (self.y, self._mask_off[0], self._mask_off[1])
         return self.bred, (self.y, self.scale, self.shift)
 
     def params(self):
@@ -312,18 +322,21 @@ class ConvUnit:
 
     # ---- backward -----------------------------------------------------------------------------------------
     def backward(self, dout: Act, sink: GradSink, training: bool, dx: Optional[Act], relu: Optional[bool] = None,
-                 add: Optional[Act] = None, bstat_for: Optional["ConvUnit"] = None, gate: Optional[Act] = None) -> None:
+                 add: Optional[Act] = None, bstat_for: Optional["ConvUnit"] = None, gate: Optional[Act] = None,
+                 plain_for: Optional["ConvUnit"] = None) -> None:
         """dout: gradient wrt the unit's output. `relu` overrides the unit's own flag (the residual unit's caller has
         already gated dout with the block's ReLU). dx (nullable): receives the input gradient, plus `add` if given.
         bstat_for: the unit whose incoming gradient dx is (and nothing else is added to it afterwards): its BatchNorm-backward
         sums come out of the epilogue of this unit's input-gradient GEMM. gate: dx is stored as zero where this tensor is <= 0
-        (the ReLU at the end of the residual block that produced this unit's input; dense per-tap GEMM only)."""
+        (the ReLU at the end of the residual block that produced this unit's input; dense per-tap GEMM only). plain_for
+        (with gate): the last unit of that block — dx, as stored, is its complete incoming gradient, so its BatchNorm-backward
+        sums (no mask of its own) come out of the same epilogue."""
         ctx, s = self.ctx, _lib.stream_ptr()
         relu = self.relu if relu is None else relu
         B = self.x.B
         if self.dy is None:
             self.dy = Act.alloc(B, self.Ho, self.Wo, self.cout, ctx.dtype, ctx.device)
-        fused = self.bred_ready and relu
+        fused = self.bred_ready and (relu != self.bred_plain)      # the slab's sums were taken with / without this unit's ReLU mask
         self.bred_ready = False
         if not fused:
             call("insar_bnrelu_bwd_reduce", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.red_part), int(relu),
@@ -350,13 +363,14 @@ class ConvUnit:
         with ctx.side_stream():
             self._weight_grad(sink.view(self.conv.weight))
         if dx is not None:
-            self._input_grad(dx, add, bstat_for, gate)
+            self._input_grad(dx, add, bstat_for, gate, plain_for)
 
     def can_gate(self) -> bool:
         """The input-gradient GEMM of this unit can apply a ReLU mask to what it stores (stride 1, per-tap GEMM)."""
         return self.s == 1 and not self.rows_bwd
 
-    def _input_grad(self, dx: Act, add: Optional[Act], bstat_for: Optional["ConvUnit"] = None, gate: Optional[Act] = None) -> None:
+    def _input_grad(self, dx: Act, add: Optional[Act], bstat_for: Optional["ConvUnit"] = None, gate: Optional[Act] = None,
+                    plain_for: Optional["ConvUnit"] = None) -> None:
         H, W = self.x.H, self.x.W
         if gate is not None and not self.can_gate():
             raise _lib.InsarError(f"{self.name}: no gated input gradient on this path")
@@ -375,6 +389,9 @@ class ConvUnit:
                 return
             if add is None and gate is None and bstat_for is not None:
                 slab = engine._igemm_bstat_slab(bstat_for, False, self.x.B * H * W, self.cin, H * W, dx)
+            elif gate is not None and plain_for is not None and engine.BSTAT_FUSE and GATE_STATS and engine._same_layout(dx, plain_for.y):
+                slab = plain_for.bstat_slab(call("insar_igemm_num_mtiles", self.x.B * H * W, self.cin), False, plain=True)
+                bstat_for = plain_for
             _igemm(self.dy, dx, self._wptr("dgrad"), self.cin, H, W, 1, taps, 0, oob=self.oob, add=add,
                    stats=slab[0] if slab else None, bstat=slab[1] if slab else None, gate=gate)
             if slab:
@@ -487,10 +504,11 @@ class BottleneckPlan:
         self.u3.backward(g, sink, training, self.dz2, relu=False, bstat_for=self.u2)
         self.u2.backward(self.dz2, sink, training, self.dz1, bstat_for=self.u1)
         if self.ud is None:
-            self.u1.backward(self.dz1, sink, training, dx, add=g, gate=gate)            # identity branch: dx = dgrad + g
+            self.u1.backward(self.dz1, sink, training, dx, add=g, gate=gate,            # identity branch: dx = dgrad + g
+                             plain_for=producer.u3 if gate is not None else None)
         else:
             self.u1.backward(self.dz1, sink, training, dx)
-            self.ud.backward(g, sink, training, dx, relu=False, add=dx, gate=gate)
+            self.ud.backward(g, sink, training, dx, relu=False, add=dx, gate=gate, plain_for=producer.u3 if gate is not None else None)
         if gate is not None:
             producer.dout_gated = True
 

@@ -145,29 +145,38 @@ def test_deeplab_train_forward_backward_against_oracle(dev, shape):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_residual_relu_gate_in_the_gemm_epilogue_is_bitwise(dev, dtype, monkeypatch):
+def test_residual_relu_gate_in_the_gemm_epilogue(dev, dtype, monkeypatch):
     """The ReLU mask of a residual block's output applied by the GEMM that writes the block's incoming gradient
-    (InsarIgemm.gate) against the pass of its own (insar_relu_gate_bwd): every parameter gradient bit for bit."""
+    (InsarIgemm.gate) against the pass of its own (insar_relu_gate_bwd): every parameter gradient bit for bit. With the
+    BatchNorm-backward sums of the block's last unit taken in the same epilogue (over the gated values as stored) the sums
+    are folded in another order: equal to rounding."""
     import insar_unet_ca_amd as iu
     from insar_unet_ca_amd import deeplab, tape
     monkeypatch.setattr(tape, "MODE", "0")
     x, y = _input((2, 1, 64, 64), 11)
-    grads = []
-    for fuse in (True, False):
+    grads, counts = [], []
+    orig = deeplab.call
+    for fuse, stats in ((False, False), (True, False), (True, True)):
         monkeypatch.setattr(deeplab, "GATE_FUSE", fuse)
+        monkeypatch.setattr(deeplab, "GATE_STATS", stats)
         net, _sd = _make(dev, 33, dtype=dtype, p_drop=0.0)
         net.train()
         calls = []
-        orig = deeplab.call
         monkeypatch.setattr(deeplab, "call", lambda name, *a: (calls.append(name), orig(name, *a))[1])
         loss = iu.CrossEntropyLoss(ignore_index=255)(net(x.to(dev)), y.to(dev))
         loss.backward()
         monkeypatch.setattr(deeplab, "call", orig)
-        n_gate = calls.count("insar_relu_gate_bwd")
-        assert n_gate == (16 if not fuse else 2), n_gate      # fused: only layer4's last block (the head writes its gradient) and layer1's last (a strided consumer)
+        counts.append((calls.count("insar_relu_gate_bwd"), calls.count("insar_bnrelu_bwd_reduce")))
         grads.append({k: p.grad.detach().clone() for k, p in net.named_parameters()})
+    # fused: only layer4's last block (the head writes its gradient) and layer1's last (a strided consumer) gate in a pass
+    assert counts[0][0] == 16 and counts[1][0] == 2 and counts[2][0] == 2, counts
+    assert counts[1][1] == counts[0][1] and counts[2][1] == counts[0][1] - 14, counts
     for k in grads[0]:
         assert torch.equal(grads[0][k], grads[1][k]), k
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    worst = max((rel_l2(grads[2][k], grads[0][k]), k) for k in grads[0] if float(grads[0][k].abs().max()) > 1e-10)
+    print("sums in the gating epilogue vs a pass of their own: worst gradient rel-L2", worst)
+    assert worst[0] <= tol, worst
 
 
 def test_deeplab_dropout_under_a_given_mask_and_adam_steps(dev):
