@@ -324,6 +324,7 @@ PROFILER: Optional[KernelTimer] = None
 SPLIT_COEF = os.environ.get("INSAR_SPLIT_COEF", "0") == "1"
 # Measured: issuing a unit's weight gradient AFTER its input-gradient GEMM ("after") is 1.2 % slower (9.34 vs 9.23 ms).
 POOL_FUSE = os.environ.get("INSAR_POOL_FUSE", "1") != "0"        # diagnostic: 0 routes the max-pool gradient with insar_maxpool2_bwd
+SMALL_WGRAD_MAIN = os.environ.get("INSAR_SMALL_WGRAD_MAIN", "1") != "0"   # the first layer's weight gradient (last launch of backward) on the main stream
 PREP_SIDE = os.environ.get("INSAR_PREP_SIDE", "1") != "0"         # diagnostic: 0 re-lays the weights out on the main stream
 OUTC_FUSE = os.environ.get("INSAR_OUTC_FUSE", "1") != "0"        # diagnostic: 0 materialises the gradient of outc's input
 WGRAD_GRID_CAP = int(os.environ.get("INSAR_WGRAD_GRID_CAP", "200"))    # 8-wave weight-gradient launches beside the dgrad chain: at most this many work-groups (0 = off)
@@ -584,6 +585,7 @@ class ConvBN:
         if x.c_len != self.cin:
             raise _lib.InsarError(f"{name}: input slice has {x.c_len} channels, conv expects {self.cin}")
         self.small = self.cin <= 4
+        self._small_part = None      # slab of the first layer's weight gradient when it runs on the main stream
         if not self.small and self.cin % 64:
             raise _lib.InsarError(f"{name}: in_channels={self.cin} must be <=4 or a multiple of 64 on the HIP path")
         if self.cout % 64:
@@ -820,14 +822,28 @@ class ConvBN:
         # weight gradient (side stream: reads x and dy, writes only the gradient sink)
         gw = sink.view(self.conv.weight)
 
+        def small_weight_grad(part):
+            nb = call("insar_conv3x3_small_wgrad_blocks", B, H)
+            cols = self.cout * self.cin * 9
+            if part is None:
+                part = ctx.wgrad_part(nb * cols)
+            elif part.numel() < nb * cols:
+                part = self._small_part = ctx.f32(nb * cols)
+            call("insar_conv3x3_small_wgrad", self.x.ref, self.dy.ref, ptr(part), _lib.stream_ptr())
+            ctx.colsum(part, gw, 1, nb, cols)
+
         def weight_grad():
+            if self.small and SMALL_WGRAD_MAIN and stage2 is None and dx is None:
+                # the first layer of the network is the LAST unit of backward: nothing is left on the main stream for its weight
+                # gradient to run beside, and on the side stream it costs two cross-queue hand-offs (about 12 us each) at the
+                # very end of the step; it runs on the main stream, with a slab of its own (the side stream's is still in use)
+                if self._small_part is None:
+                    self._small_part = ctx.f32(1)
+                small_weight_grad(self._small_part)
+                return
             with ctx.side_stream():
                 if self.small:
-                    nb = call("insar_conv3x3_small_wgrad_blocks", B, H)
-                    cols = self.cout * self.cin * 9
-                    part = ctx.wgrad_part(nb * cols)
-                    call("insar_conv3x3_small_wgrad", self.x.ref, self.dy.ref, ptr(part), _lib.stream_ptr())
-                    ctx.colsum(part, gw, 1, nb, cols)
+                    small_weight_grad(None)
                 else:
                     _wgrad_conv3(ctx, self.x, self.dy, gw)
                 if stage2 is not None:
