@@ -239,6 +239,14 @@ int insar_conv3x3_small_fwd(const InsarAct* x, const float* w /*torch (Co,Ci,3,3
 /* part: [insar_conv3x3_small_wgrad_blocks(B,H)][Co*Ci*9] partial rows (torch (Co,Ci,3,3) order). */
 int insar_conv3x3_small_wgrad_blocks(int32_t B, int32_t H);
 int insar_conv3x3_small_wgrad(const InsarAct* x, const InsarAct* dy, float* part, void* stream);
+/* The same with the unit's BatchNorm / ReLU backward apply pass (insar_bnrelu_bwd_apply without an SE gate) evaluated on the
+ * way in: dy — which only this launch would read, the network's first layer having no input gradient (:81 under :345) — is never
+ * written. g: the unit's incoming gradient, y: its conv output; bf16, Cin = 2, Cout = 64, W % 64 == 0 (insar_..._fused_ok).
+ * Bit for bit the two launches it replaces. */
+int insar_conv3x3_small_wgrad_fused_ok(const InsarAct* x, const InsarAct* y);
+int insar_conv3x3_small_wgrad_fused(const InsarAct* x, const InsarAct* g, const InsarAct* y, const float* scale,
+                                    const float* shift, const float* mean, const float* invstd, const float* k1,
+                                    const float* k2, int32_t relu, float* part, void* stream);
 
 /* ---- segmented column sum of partial slabs: out[s][c] (+)= sum_r part[s][r][c] ---------------
  * Two-stage (deterministic, no atomics) when rows > 256: stage 1 writes into `tmp`

@@ -120,6 +120,8 @@ _SIGNATURES = {
     "insar_conv3x3_small_fwd_rows": [_AP, _AP],
     "insar_conv3x3_small_wgrad_blocks": [_I, _I],
     "insar_conv3x3_small_wgrad": [_AP, _AP, _P, _P],
+    "insar_conv3x3_small_wgrad_fused_ok": [_P, _P],
+    "insar_conv3x3_small_wgrad_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "insar_colsum": [_P, _P, _I, _L, _I, _I, _P, _L, _P],
     "insar_colsum_partial": [_P, _P, _L, _I, _I, _P],
     "insar_bn_finalize": [C.POINTER(InsarBnFinalize), _P],
@@ -215,7 +217,7 @@ def load():
     return lib
 
 
-_COUNT_ONLY = {"insar_tune_get", "insar_igemm_num_mtiles", "insar_igemm_tile_rows", "insar_igemm_tile_cols", "insar_igemm_tile_cols_dt", "insar_wgrad_tile", "insar_wgrad_tile_pair", "insar_wgrad_conv3_tile", "insar_conv3x3_flat_ok", "insar_conv3x3_flat_rows_ok", "insar_conv3x3_flat_rows_dil_ok", "insar_conv3x3_flat_num_mtiles", "insar_conv3x3_flat_stat_rows", "insar_conv3x3_c64_ok", "insar_conv3x3_c64_rows", "insar_conv3x3_c64_geometry", "insar_conv3x3_small_wgrad_blocks", "insar_conv3x3_small_fwd_rows", "insar_conv1x1_out_bwd_blocks",
+_COUNT_ONLY = {"insar_tune_get", "insar_igemm_num_mtiles", "insar_igemm_tile_rows", "insar_igemm_tile_cols", "insar_igemm_tile_cols_dt", "insar_wgrad_tile", "insar_wgrad_tile_pair", "insar_wgrad_conv3_tile", "insar_conv3x3_flat_ok", "insar_conv3x3_flat_rows_ok", "insar_conv3x3_flat_rows_dil_ok", "insar_conv3x3_flat_num_mtiles", "insar_conv3x3_flat_stat_rows", "insar_conv3x3_c64_ok", "insar_conv3x3_c64_rows", "insar_conv3x3_c64_geometry", "insar_conv3x3_small_wgrad_blocks", "insar_conv3x3_small_wgrad_fused_ok", "insar_conv3x3_small_fwd_rows", "insar_conv1x1_out_bwd_blocks",
                "insar_ce_blocks", "insar_conv7x7s2_fwd_rows", "insar_conv7x7s2_wgrad_blocks"}
 
 

@@ -457,8 +457,14 @@ struct SmallWgradMfmaArgs {
   int H, W, Wp, spr;                 // spr = W / 64 K steps per image row
   int Cx, cx_off, Cdy, cdy_off;
   int ksteps;                        // B * H * spr
+  // FUSED: dy is never in memory — the BatchNorm / ReLU backward apply pass of the unit (pointwise.hip,
+  // bnrelu_bwd_apply_kernel, no SE gate) is evaluated on the way into the LDS tile from the unit's incoming gradient g
+  // (a.dy, Cdy, cdy_off describe g) and its conv output y
+  const char* y; int Cy, cy_off, relu;
+  const float* scale; const float* shift; const float* mean; const float* invstd; const float* k1; const float* k2;
 };
 
+template <bool FUSED>
 __global__ __launch_bounds__(SWM_WAVES * 64, 2) void conv3x3_small_wgrad_mfma_kernel(SmallWgradMfmaArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -496,6 +502,45 @@ __global__ __launch_bounds__(SWM_WAVES * 64, 2) void conv3x3_small_wgrad_mfma_ke
       lds_dma16_untracked(ybase + (p0 + row) * ypitch + ((ypos ^ (((row >> 1) & 3) << 1)) << 4), ldsW + buf * SWM_Y_TILE + i * 1024);
     }
   };
+  // FUSED: this lane's eight (g, y) chunks of a step — rows 8i + yrow, the source chunk its LDS position holds (the XOR term
+  // depends on yrow only, so the lane's eight channels and their constants are fixed) — and the apply pass's constants
+  const int ychunk = ypos ^ (((yrow >> 1) & 3) << 1);
+  uint4 vg[FUSED ? 8 : 1], vy[FUSED ? 8 : 1];
+  float sc[FUSED ? 8 : 1], sh[FUSED ? 8 : 1], a0[FUSED ? 8 : 1], a1[FUSED ? 8 : 1];
+  if constexpr (FUSED) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = ychunk * 8 + j;
+      sc[j] = a.scale[c]; sh[j] = a.shift[c];
+      a1[j] = -sc[j] * a.invstd[c] * a.k2[c];
+      a0[j] = -sc[j] * a.k1[c] - a1[j] * a.mean[c];
+    }
+  }
+  const long long gpitch = ypitch, y2pitch = (long long)a.Cy * 2;
+  const char* y2base = FUSED ? a.y + (long long)a.cy_off * 2 : nullptr;
+  auto load_gy = [&](long long p0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long long pix = p0 + i * 8 + yrow;
+      vg[i] = *(const uint4*)(ybase + pix * gpitch + (ychunk << 4));
+      vy[i] = *(const uint4*)(y2base + pix * y2pitch + (ychunk << 4));
+    }
+  };
+  auto write_dy = [&](int buf) {                      // dy = (mask ? g * scale : 0) + (a0 + a1 * y), rounded to bf16 as the pass stores it
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float f[8], gg[8], o[8];
+      Chunk<bf16_t>::unpack(vy[i], f);
+      Chunk<bf16_t>::unpack(vg[i], gg);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool on = !a.relu || fmaf(f[j], sc[j], sh[j]) > 0.f;
+        const float ge = on ? fmaf(gg[j], sc[j], 0.f) : 0.f;
+        o[j] = ge + fmaf(f[j], a1[j], a0[j]);
+      }
+      *(uint4*)(sW + buf * SWM_Y_TILE + i * 1024 + lane * 16) = Chunk<bf16_t>::pack(o);
+    }
+  };
   uint32_t xq[9];
   auto load_x = [&](long long p0) {
     const char* xc = xbase + (p0 + lane) * xpitch;            // this lane's pixel; taps at uniform offsets
@@ -511,7 +556,7 @@ __global__ __launch_bounds__(SWM_WAVES * 64, 2) void conv3x3_small_wgrad_mfma_ke
 
   if (ks0 < ks1) {
     const long long p0 = first_pixel(ks0);
-    stage_y(0, p0);
+    if constexpr (FUSED) load_gy(p0); else stage_y(0, p0);
     load_x(p0);
   }
   const int pswz = (lane >> 2) & 3;                             // patch-tile swizzle of this lane's row (row = lane)
@@ -523,10 +568,11 @@ __global__ __launch_bounds__(SWM_WAVES * 64, 2) void conv3x3_small_wgrad_mfma_ke
     // (inline-asm) LDS-DMA issue would make it wait for the next tile as well.
 #pragma unroll
     for (int t = 0; t < 9; ++t) *(uint32_t*)(sP + lane * 64 + (((t >> 2) ^ pswz) << 4) + (t & 3) * 4) = xq[t];
+    if constexpr (FUSED) write_dy(buf);
     __builtin_amdgcn_sched_barrier(0);
     if (ks + 1 < ks1) {                                         // next step's loads fly during this step's LDS reads and MFMAs
       const long long p1 = first_pixel(ks + 1);
-      stage_y(buf ^ 1, p1);
+      if constexpr (FUSED) load_gy(p1); else stage_y(buf ^ 1, p1);
       load_x(p1);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the tile is this wave's own: no barrier
@@ -603,16 +649,16 @@ extern "C" int insar_conv3x3_small_wgrad(const InsarAct* x, const InsarAct* dy, 
   if (small_wgrad_uses_mfma(x, dy)) {
     static std::atomic<uint64_t> attr_mask{0};     // per-device, see common.h
     const int lds_bytes = SWM_WAVES * SWM_WAVE_LDS;
-    hipError_t e = insar_set_lds_once(attr_mask, (const void*)conv3x3_small_wgrad_mfma_kernel, lds_bytes);
+    hipError_t e = insar_set_lds_once(attr_mask, (const void*)conv3x3_small_wgrad_mfma_kernel<false>, lds_bytes);
     if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_conv3x3_small_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    SmallWgradMfmaArgs a;
+    SmallWgradMfmaArgs a = {};
     a.x = (const char*)x->ptr; a.dy = (const char*)dy->ptr; a.part = part;
     a.H = x->H; a.W = x->W; a.Wp = x->W + 2; a.spr = x->W / 64;
     a.Cx = x->C; a.cx_off = x->c_off; a.Cdy = dy->C; a.cdy_off = dy->c_off;
     const long long ksteps = (long long)x->B * x->H * a.spr;
     if (ksteps > 0x7fffffffLL) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_small_wgrad: too many pixels");
     a.ksteps = (int)ksteps;
-    hipLaunchKernelGGL(conv3x3_small_wgrad_mfma_kernel, dim3(grid), dim3(SWM_WAVES * 64), lds_bytes, s, a);
+    hipLaunchKernelGGL(conv3x3_small_wgrad_mfma_kernel<false>, dim3(grid), dim3(SWM_WAVES * 64), lds_bytes, s, a);
     INSAR_CHECK_LAUNCH("insar_conv3x3_small_wgrad");
     return INSAR_OK;
   }
@@ -625,6 +671,43 @@ extern "C" int insar_conv3x3_small_wgrad(const InsarAct* x, const InsarAct* dy, 
     else hipLaunchKernelGGL((conv3x3_small_wgrad_kernel<float, 1>), dim3(grid), dim3(DR_THREADS), lds, s, make_view(*x), make_view(*dy), part);
   }
   INSAR_CHECK_LAUNCH("insar_conv3x3_small_wgrad");
+  return INSAR_OK;
+}
+
+// The same weight gradient with the unit's BatchNorm / ReLU backward apply pass evaluated on the way in: dy (which only this
+// launch would read: the network's first layer has no input gradient) is never written. g: the unit's incoming gradient,
+// y: its conv output (bf16, 64 channels each). Results are bit for bit those of insar_bnrelu_bwd_apply + insar_conv3x3_small_wgrad.
+extern "C" int insar_conv3x3_small_wgrad_fused_ok(const InsarAct* x, const InsarAct* y) {
+  if (!x || !y) return 0;
+  return small_wgrad_uses_mfma(x, y) ? 1 : 0;
+}
+
+extern "C" int insar_conv3x3_small_wgrad_fused(const InsarAct* x, const InsarAct* g, const InsarAct* y, const float* scale,
+                                               const float* shift, const float* mean, const float* invstd, const float* k1,
+                                               const float* k2, int32_t relu, float* part, void* stream) {
+  int rc;
+  if ((rc = check_small(x, y, "insar_conv3x3_small_wgrad_fused"))) return rc;
+  if (!g || !g->ptr || !part || !scale || !shift || !mean || !invstd || !k1 || !k2)
+    INSAR_FAIL(INSAR_E_ARG, "insar_conv3x3_small_wgrad_fused: null pointer");
+  if ((rc = insar_check_act(g, "insar_conv3x3_small_wgrad_fused", "g"))) return rc;
+  if (!small_wgrad_uses_mfma(x, y) || !small_wgrad_uses_mfma(x, g) || g->B != y->B || g->H != y->H || g->W != y->W)
+    INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_small_wgrad_fused: bf16, Cin = 2, Cout = 64, W %% 64 == 0, g and y on one grid");
+  static std::atomic<uint64_t> attr_mask{0};     // per-device, see common.h
+  const int lds_bytes = SWM_WAVES * SWM_WAVE_LDS;
+  hipError_t e = insar_set_lds_once(attr_mask, (const void*)conv3x3_small_wgrad_mfma_kernel<true>, lds_bytes);
+  if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_conv3x3_small_wgrad_fused: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  SmallWgradMfmaArgs a = {};
+  a.x = (const char*)x->ptr; a.dy = (const char*)g->ptr; a.part = part;
+  a.H = x->H; a.W = x->W; a.Wp = x->W + 2; a.spr = x->W / 64;
+  a.Cx = x->C; a.cx_off = x->c_off; a.Cdy = g->C; a.cdy_off = g->c_off;
+  a.y = (const char*)y->ptr; a.Cy = y->C; a.cy_off = y->c_off; a.relu = relu ? 1 : 0;
+  a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.k1 = k1; a.k2 = k2;
+  const long long ksteps = (long long)x->B * x->H * a.spr;
+  if (ksteps > 0x7fffffffLL) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_small_wgrad_fused: too many pixels");
+  a.ksteps = (int)ksteps;
+  const int grid = insar_conv3x3_small_wgrad_blocks(y->B, y->H);
+  hipLaunchKernelGGL(conv3x3_small_wgrad_mfma_kernel<true>, dim3(grid), dim3(SWM_WAVES * 64), lds_bytes, (hipStream_t)stream, a);
+  INSAR_CHECK_LAUNCH("insar_conv3x3_small_wgrad_fused");
   return INSAR_OK;
 }
 

@@ -324,6 +324,7 @@ PROFILER: Optional[KernelTimer] = None
 SPLIT_COEF = os.environ.get("INSAR_SPLIT_COEF", "0") == "1"
 # Measured: issuing a unit's weight gradient AFTER its input-gradient GEMM ("after") is 1.2 % slower (9.34 vs 9.23 ms).
 POOL_FUSE = os.environ.get("INSAR_POOL_FUSE", "1") != "0"        # diagnostic: 0 routes the max-pool gradient with insar_maxpool2_bwd
+SMALL_WGRAD_FUSE = os.environ.get("INSAR_SMALL_WGRAD_FUSE", "1") != "0"   # ... with the unit's BatchNorm-backward apply pass evaluated inside it (dy never written)
 SMALL_WGRAD_MAIN = os.environ.get("INSAR_SMALL_WGRAD_MAIN", "1") != "0"   # the first layer's weight gradient (last launch of backward) on the main stream
 PREP_SIDE = os.environ.get("INSAR_PREP_SIDE", "1") != "0"         # diagnostic: 0 re-lays the weights out on the main stream
 OUTC_FUSE = os.environ.get("INSAR_OUTC_FUSE", "1") != "0"        # diagnostic: 0 materialises the gradient of outc's input
@@ -754,7 +755,13 @@ class ConvBN:
         that gradient from dlogits instead of reading a 64-channel tensor (csrc/pointwise.hip, OutcGrad)."""
         ctx, s = self.ctx, _lib.stream_ptr()
         B, H, W = self.x.B, self.x.H, self.x.W
-        if self.dy is None:
+        # the network's first layer: nobody but its own weight gradient reads dy, so the apply pass is evaluated inside the
+        # weight-gradient kernel and dy is never written (insar_conv3x3_small_wgrad_fused; bit for bit the two launches)
+        fuse_small = (self.small and SMALL_WGRAD_FUSE and SMALL_WGRAD_MAIN and dx is None and se is None and outc_grad is None
+                      and pool_grad is None and dout is not None and not (training and SPLIT_COEF)
+                      and call("insar_conv3x3_small_wgrad_fused_ok", self.x.ref, self.y.ref) == 1
+                      and call("insar_conv3x3_small_wgrad_fused_ok", self.x.ref, dout.ref) == 1)
+        if self.dy is None and not fuse_small:
             self.dy = Act.alloc(B, H, W, self.cout, ctx.dtype, ctx.device)
         if outc_grad is not None:
             # (dlogits, outc weight, K[, gate, wpart]): with wpart the reduce pass also writes the output conv's own
@@ -816,9 +823,10 @@ class ConvBN:
         else:
             self._coef(coef_args, s, se)
             self._sync_k()
-            call("insar_bnrelu_bwd_apply", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.mean),
-                 ptr(self.invstd), ptr(se.gate) if se else 0, ptr(se.coefB) if se else 0, ptr(self.k1), ptr(self.k2),
-                 self.dy.ref, 1, s)
+            if not fuse_small:
+                call("insar_bnrelu_bwd_apply", dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift), ptr(self.mean),
+                     ptr(self.invstd), ptr(se.gate) if se else 0, ptr(se.coefB) if se else 0, ptr(self.k1), ptr(self.k2),
+                     self.dy.ref, 1, s)
         # weight gradient (side stream: reads x and dy, writes only the gradient sink)
         gw = sink.view(self.conv.weight)
 
@@ -829,7 +837,11 @@ class ConvBN:
                 part = ctx.wgrad_part(nb * cols)
             elif part.numel() < nb * cols:
                 part = self._small_part = ctx.f32(nb * cols)
-            call("insar_conv3x3_small_wgrad", self.x.ref, self.dy.ref, ptr(part), _lib.stream_ptr())
+            if fuse_small:
+                call("insar_conv3x3_small_wgrad_fused", self.x.ref, dout.ref, self.y.ref, ptr(self.scale), ptr(self.shift),
+                     ptr(self.mean), ptr(self.invstd), ptr(self.k1), ptr(self.k2), 1, ptr(part), _lib.stream_ptr())
+            else:
+                call("insar_conv3x3_small_wgrad", self.x.ref, self.dy.ref, ptr(part), _lib.stream_ptr())
             ctx.colsum(part, gw, 1, nb, cols)
 
         def weight_grad():

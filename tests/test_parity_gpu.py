@@ -1320,6 +1320,34 @@ def test_pool_gradient_inside_bn_backward_is_bitwise_maxpool2_bwd(dev, dtype, mo
     assert all(torch.equal(a, b) for a, b in zip(*grads))
 
 
+def test_first_layer_weight_gradient_with_the_apply_pass_inside_is_bitwise(dev, monkeypatch):
+    """insar_conv3x3_small_wgrad_fused (BatchNorm / ReLU backward of the first unit evaluated on the way into the weight
+    gradient's LDS tile, dy never written) against the apply pass + insar_conv3x3_small_wgrad: same gradient bits
+    (bf16, W % 64 == 0: the shapes the fused kernel takes; other shapes keep the two launches)."""
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd import engine
+    from insar_unet_ca_amd.data import make_batch
+    x, y = make_batch(7, 3, 64)
+    x, y = x.to(dev), y.to(dev)
+    grads = []
+    for fuse in (True, False):
+        monkeypatch.setattr(engine, "SMALL_WGRAD_FUSE", fuse)
+        torch.manual_seed(5)
+        net = iu.UNet(2, 2, True, compute_dtype=torch.bfloat16).to(dev).train()
+        calls = []
+        orig = engine.call
+        monkeypatch.setattr(engine, "call", lambda name, *a: (calls.append(name), orig(name, *a))[1])
+        loss = iu.DiceCELoss(ignore_index=255)(net(x), y)
+        loss.backward()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(engine, "call", orig)
+        assert calls.count("insar_conv3x3_small_wgrad_fused") == (1 if fuse else 0)
+        assert calls.count("insar_conv3x3_small_wgrad") == (0 if fuse else 1)
+        assert (net._plan(x).enc[0].u1.dy is None) == fuse           # dy of the first unit is not even allocated
+        grads.append([p.grad.clone() for p in net.parameters()])
+    assert all(torch.equal(a, b) for a, b in zip(*grads))
+
+
 def test_step_reproducible_over_many_runs_with_side_stream(dev):
     """Race screen for the two-stream step (weight gradients beside the dgrad chain): 150 repeats of fwd+bwd on
     fixed weights must give ONE set of gradient bits. (Regression: a wave passed the K-step barrier of the 64x64
