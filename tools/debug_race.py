@@ -43,7 +43,9 @@ def snapshot(lg):
         for un, u in (("u1", blk.u1), ("u2", blk.u2)):
             out[f"{nm}.{un}.y"] = csum(u.y.buf); out[f"{nm}.{un}.stats"] = csum(u.stats)
             out[f"{nm}.{un}.scale"] = csum(u.scale)
-            out[f"{nm}.{un}.dy"] = csum(u.dy.buf); out[f"{nm}.{un}.k1"] = csum(u.k1); out[f"{nm}.{un}.red"] = csum(u.red_part)
+            if u.dy is not None:         # (the first unit's dy is never written: its apply pass runs inside its weight-gradient kernel)
+                out[f"{nm}.{un}.dy"] = csum(u.dy.buf)
+            out[f"{nm}.{un}.k1"] = csum(u.k1); out[f"{nm}.{un}.red"] = csum(u.red_part)
         out[f"{nm}.z1"] = csum(blk.z1.buf); out[f"{nm}.out"] = csum(blk.out.buf); out[f"{nm}.dz1"] = csum(blk.dz1.buf)
         if blk.se:
             out[f"{nm}.gate"] = csum(blk.se.gate)
