@@ -491,6 +491,9 @@ int insar_relu_gate_bwd(const InsarAct* dout, const InsarAct* out, const InsarAc
 /* ASPP pooling branch: out (B,1,1,C) = factor * sum_hw x;  dst (B,H,W,C) (+)= factor * src (B,1,1,C). */
 int insar_sum_hw(const InsarAct* x, const InsarAct* out, float factor, void* stream);
 int insar_broadcast_hw(const InsarAct* src, const InsarAct* dst, float factor, int32_t accumulate, void* stream);
+/* the same, storing zero where `gate` (dst's grid, channels and dtype) is <= 0: the ReLU mask of the residual block whose incoming
+ * gradient dst is, applied by its last writer (ABI 4; InsarIgemm.gate is the GEMM writers' form) */
+int insar_broadcast_hw_gate(const InsarAct* src, const InsarAct* dst, const InsarAct* gate, float factor, int32_t accumulate, void* stream);
 /* Dropout(p): make_mask != 0 draws mask[B][H][W][c_len] from (seed, element index) and stores it; == 0 applies `mask`. */
 int insar_dropout(const InsarAct* x, const InsarAct* dst, uint8_t* mask, uint64_t seed, const int64_t* counter /*nullable, device:
                   mixed into the seed so that every replay of a captured step draws a new mask*/, float p, int32_t make_mask, void* stream);

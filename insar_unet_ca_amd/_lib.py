@@ -174,6 +174,7 @@ _SIGNATURES = {
     "insar_relu_gate_bwd": [_AP, _AP, _AP, _P],
     "insar_sum_hw": [_AP, _AP, _F, _P],
     "insar_broadcast_hw": [_AP, _AP, _F, _I, _P],
+    "insar_broadcast_hw_gate": [_AP, _AP, _AP, _F, _I, _P],
     "insar_dropout": [_AP, _AP, _P, C.c_uint64, _P, _F, _I, _P],
     "insar_bilinear_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "insar_bilinear_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],

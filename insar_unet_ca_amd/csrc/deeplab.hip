@@ -491,8 +491,9 @@ extern "C" int insar_sum_hw(const InsarAct* x, const InsarAct* out, float factor
 
 // dst[n,h,w,c] = (accumulate ? dst : 0) + factor * src[n,0,0,c]: bilinear up-sampling of a 1x1 map (forward of the pooling
 // branch, accumulate = 0) and the gradient of the global average (accumulate = 1, factor = 1/HW).
+// gate (has_gate): the result is stored as zero where gate <= 0 (the ReLU mask of the residual block whose incoming gradient dst is)
 template <typename T, typename TS>
-__global__ void broadcast_hw_kernel(ActView src, ActView dst, float factor, int accumulate) {
+__global__ void broadcast_hw_kernel(ActView src, ActView dst, float factor, int accumulate, ActView gate, int has_gate) {
   constexpr int CH = Chunk<T>::N;
   const int cpp = dst.c_len / CH;
   const int total = dst.W * cpp;
@@ -515,24 +516,48 @@ __global__ void broadcast_hw_kernel(ActView src, ActView dst, float factor, int 
 #pragma unroll
         for (int j = 0; j < CH; ++j) f[j] *= factor;
       }
+      if (has_gate) {
+        float q[CH];
+        Chunk<T>::unpack(*dl_chunk<T>(gate, n, h, w, cc), q);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) f[j] = q[j] > 0.f ? f[j] : 0.f;
+      }
       *dl_chunk_w<T>(dst, n, h, w, cc) = Chunk<T>::pack(f);
     }
   }
 }
 
 /* src may be fp32 while dst is bf16 (see insar_sum_hw). */
+static int broadcast_hw_impl(const InsarAct* src, const InsarAct* dst, const InsarAct* gate, float factor, int32_t accumulate, void* stream);
 extern "C" int insar_broadcast_hw(const InsarAct* src, const InsarAct* dst, float factor, int32_t accumulate, void* stream) {
+  return broadcast_hw_impl(src, dst, nullptr, factor, accumulate, stream);
+}
+/* the same, storing zero where `gate` (dst's grid, channels and dtype) is <= 0: the last writer of a residual block's incoming
+ * gradient applies the block's ReLU mask (as InsarIgemm.gate does for the GEMM writers) */
+extern "C" int insar_broadcast_hw_gate(const InsarAct* src, const InsarAct* dst, const InsarAct* gate, float factor, int32_t accumulate,
+                                       void* stream) {
+  if (!gate) INSAR_FAIL(INSAR_E_ARG, "insar_broadcast_hw_gate: null gate");
+  return broadcast_hw_impl(src, dst, gate, factor, accumulate, stream);
+}
+static int broadcast_hw_impl(const InsarAct* src, const InsarAct* dst, const InsarAct* gate, float factor, int32_t accumulate, void* stream) {
   int rc;
   if ((rc = insar_check_act(src, "insar_broadcast_hw", "src"))) return rc;
   if ((rc = insar_check_act(dst, "insar_broadcast_hw", "dst"))) return rc;
   if (src->B != dst->B || src->H != 1 || src->W != 1 || src->c_len != dst->c_len)
     INSAR_FAIL(INSAR_E_SHAPE, "insar_broadcast_hw: src must be the (B, 1, 1, C) slice of dst's channels");
   if (src->dtype != dst->dtype && src->dtype != INSAR_F32) INSAR_FAIL(INSAR_E_DTYPE, "insar_broadcast_hw: src must have dst's dtype or be fp32");
+  if (gate) {
+    if ((rc = insar_check_act(gate, "insar_broadcast_hw_gate", "gate"))) return rc;
+    if (gate->dtype != dst->dtype || gate->B != dst->B || gate->H != dst->H || gate->W != dst->W || gate->c_len != dst->c_len)
+      INSAR_FAIL(INSAR_E_SHAPE, "insar_broadcast_hw_gate: gate must have dst's grid, channels and dtype");
+  }
   int grid = insar_grid_cap((int64_t)dst->B * dst->H);
   hipStream_t s = (hipStream_t)stream;
-  if (dst->dtype == INSAR_BF16 && src->dtype == INSAR_BF16) hipLaunchKernelGGL((broadcast_hw_kernel<bf16_t, bf16_t>), dim3(grid), dim3(DL_THREADS), 0, s, make_view(*src), make_view(*dst), factor, accumulate);
-  else if (dst->dtype == INSAR_BF16) hipLaunchKernelGGL((broadcast_hw_kernel<bf16_t, float>), dim3(grid), dim3(DL_THREADS), 0, s, make_view(*src), make_view(*dst), factor, accumulate);
-  else hipLaunchKernelGGL((broadcast_hw_kernel<float, float>), dim3(grid), dim3(DL_THREADS), 0, s, make_view(*src), make_view(*dst), factor, accumulate);
+  const ActView gv = gate ? make_view(*gate) : make_view(*dst);
+  const int hg = gate ? 1 : 0;
+  if (dst->dtype == INSAR_BF16 && src->dtype == INSAR_BF16) hipLaunchKernelGGL((broadcast_hw_kernel<bf16_t, bf16_t>), dim3(grid), dim3(DL_THREADS), 0, s, make_view(*src), make_view(*dst), factor, accumulate, gv, hg);
+  else if (dst->dtype == INSAR_BF16) hipLaunchKernelGGL((broadcast_hw_kernel<bf16_t, float>), dim3(grid), dim3(DL_THREADS), 0, s, make_view(*src), make_view(*dst), factor, accumulate, gv, hg);
+  else hipLaunchKernelGGL((broadcast_hw_kernel<float, float>), dim3(grid), dim3(DL_THREADS), 0, s, make_view(*src), make_view(*dst), factor, accumulate, gv, hg);
   INSAR_CHECK_LAUNCH("insar_broadcast_hw");
   return INSAR_OK;
 }

@@ -780,7 +780,12 @@ class DeepLabPlan(tape.PlanTape):
         self.pool_unit.backward(dzp, sink, training, dgp)
         for i, u in enumerate(self.branches):
             u.backward(dcat.slice(256 * i, 256), sink, training, dx5, add=dx5 if i > 0 else None)
-        call("insar_broadcast_hw", dgp.ref, dx5.ref, 1.0 / (self.x5.H * self.x5.W), 1, s)
+        last = self.blocks[-1]
+        if GATE_FUSE and last.out is self.x5:      # the last writer of layer4's incoming gradient applies the last block's ReLU mask
+            call("insar_broadcast_hw_gate", dgp.ref, dx5.ref, last.out.ref, 1.0 / (self.x5.H * self.x5.W), 1, s)
+            last.dout_gated = True
+        else:
+            call("insar_broadcast_hw", dgp.ref, dx5.ref, 1.0 / (self.x5.H * self.x5.W), 1, s)
         if on_bucket is not None:
             on_bucket(self, ("aspp", 0))
         # residual layers, last to first
