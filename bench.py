@@ -15,11 +15,6 @@ import os
 import sys
 import time
 
-# Kernel arguments in device memory (the HIP runtime's setting for MI300-class parts; the default of this ROCm image — a box whose
-# environment turned it off would enqueue every launch 1 us slower: same-box 7.05 vs 7.30 ms/step, profiles/r03_pass_latency_tuning.txt
-# item 24). Must be in the environment before the runtime loads with torch; an explicit setting of the caller is respected.
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
-
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
