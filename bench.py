@@ -413,6 +413,12 @@ def main() -> int:
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip configs 4 and 5 (the default 1-GPU run of config 2 reports them under `other_configs`)")
     ap.add_argument("--bucket-mb", type=float, default=16.0, help="N > 1: minimum size of a gradient-exchange bucket (MiB)")
+    ap.add_argument("--allow-switches", action="store_true",
+                    help="measure although INSAR_* environment switches that select kernels / launch paths are set to non-default "
+                         "values (A/B runs); without it such a run exits with code 3. The line reports them under `switches` either way")
+    ap.add_argument("--wgrad-fill", type=float, default=None,
+                    help="share of the work-group slots a side-stream weight gradient aims at (engine.WGRAD_FILL, default 0.6; the "
+                         "transposed convs' 0.7 scales with it): the 8-GPU operator's knob for trading side-queue CUs against RCCL's")
     ap.add_argument("--stream-input", action="store_true",
                     help="feed every step from the host: batches in pinned memory, copied on a copy stream while the previous "
                          "step computes (the reference copies per step, Unet-ChannalAttention.py:339-340)")
@@ -436,8 +442,23 @@ def main() -> int:
     import torch.distributed as dist
 
     import insar_unet_ca_amd as iu
-    from insar_unet_ca_amd import engine
+    from insar_unet_ca_amd import engine, switches
     from insar_unet_ca_amd.data import make_batch
+
+    # every INSAR_* variable that is set to something other than its default goes into the line; a default run refuses to
+    # measure with a kernel-selecting one set (a stray variable on a box would otherwise change the measurement without trace)
+    sw = switches.non_default([os.path.abspath(__file__)])
+    selecting = [k for k, v in sw.items() if v["kernel_selecting"]]
+    if selecting and not args.allow_switches:
+        print(f"error: non-default kernel-selecting switches in the environment: {', '.join(selecting)} "
+              "(unset them, or pass --allow-switches for an A/B run)", file=sys.stderr)
+        return 3
+    if args.wgrad_fill is not None:
+        if not 0.05 <= args.wgrad_fill <= 1.0:
+            print("error: --wgrad-fill must lie in [0.05, 1]", file=sys.stderr)
+            return 2
+        engine.WGRAD_FILL_T = min(1.0, engine.WGRAD_FILL_T * args.wgrad_fill / engine.WGRAD_FILL)
+        engine.WGRAD_FILL = args.wgrad_fill
 
     if world > 1:
         if args.backend == "nccl":
@@ -449,6 +470,8 @@ def main() -> int:
     if isinstance(out, int):
         return out
     if rank == 0 and isinstance(out, dict):
+        out["switches"] = {k: v["value"] for k, v in sw.items()}
+        out["wgrad_fill"] = {"conv3x3": engine.WGRAD_FILL, "conv_transpose": engine.WGRAD_FILL_T, "deeplab": engine.WGRAD_FILL_DL}
         if world == 1 and not args.no_other_configs and args.model == "unet" and args.dtype == "bf16" and args.size == 256:
             out["other_configs"] = other_configs(args, dev, dist, iu, engine, make_batch)
         if world == 1 and not args.no_cpu_baseline and args.model == "unet":

@@ -152,7 +152,8 @@ int insar_conv3x3_flat_num_mtiles(const InsarAct* x);
  * pixels, so that the three dx taps share one staged tile as in the flat geometry while the tile count is M / 256 (the deep
  * levels of the U-Net, where the flat geometry's 254-pixel step breaks the one-round-of-work-groups grid). Needs W a power
  * of two in 16..256 and H a multiple of 256 / W: insar_conv3x3_flat_rows_ok. flip bit 4 = 16: 64-column tiles whatever N.
- * The statistics slab has insar_conv3x3_flat_stat_rows(x, N, flip) rows, with the same bits. */
+ * The statistics slab has insar_conv3x3_flat_stat_rows(x, N, flip) rows, with the same bits. Row tiles need K and N multiples
+ * of 64 and have no persistent form: flip bit 2 together with bit 3 is INSAR_E_ARG. */
 int insar_conv3x3_flat_rows_ok(const InsarAct* x, int32_t N);
 /* Row tiles of a DILATED 3x3 convolution (padding = dilation; flip bits 8-11 carry the dilation, 0 = 1): taps that reach beyond
  * the one-pixel halo read zeros, as insar_igemm's INSAR_IGEMM_OOB_ZERO. Needs 256 / W * (W + 2 * dil) <= 320 besides the above. */
@@ -214,6 +215,13 @@ int insar_wgrad(const InsarWgrad* d, void* stream);
  * nor 16 / 32). */
 int insar_wgrad_conv3_tile(const InsarAct* x, int32_t Cout);
 int insar_wgrad_conv3(const InsarAct* x, const InsarAct* dy, float* part, int32_t nsplit, void* stream);
+/* The same slabs again (bit for bit insar_wgrad_conv3's at the same nsplit) for the bf16 layers with >= 256 channels on one
+ * side and >= 128 on the other, from 256 x 128 (Cin x Cout; 128 x 256 where only Cout has 256) tiles: 8 waves of 64 x 64 x
+ * three taps, a K step as six [fragment reads + LDS-DMA issue | 16 MFMAs] phases with the two waves of a SIMD in opposite
+ * roles, a three-slot LDS ring whose only vector-memory wait is a counted one per K step (csrc/wgrad3x.hip).
+ * insar_wgrad_conv3x_tile: (tile(Cin) << 16) | tile(Cout), or 0 where the layer keeps insar_wgrad_conv3. */
+int insar_wgrad_conv3x_tile(const InsarAct* x, int32_t Cout);
+int insar_wgrad_conv3x(const InsarAct* x, const InsarAct* dy, float* part, int32_t nsplit, void* stream);
 /* grad = sum_split part[...] re-laid out to the torch parameter layout.
  * layout 0: Conv2d (Co,Ci,kh,kw): grad[(co*Ci+ci)*ntaps + tap]
  * layout 1: ConvTranspose2d (Ci,Co,2,2): grad[(ci*Co+co)*ntaps + tap]
@@ -253,6 +261,10 @@ int insar_conv3x3_small_wgrad_fused(const InsarAct* x, const InsarAct* g, const 
  * (>= ceil(rows/128)*segments*cols floats), stage 2 folds it. */
 int insar_colsum(const float* part, float* out, int32_t segments, int64_t rows, int32_t cols,
                  int32_t accumulate, float* tmp, int64_t tmp_floats, void* stream);
+/* The same over the first `cols` columns of rows that are `ld` >= cols floats apart: a bias / 1x1-weight gradient summed
+ * straight into its place in the flat gradient buffer (no staging tensor and no device copy behind it). */
+int insar_colsum_ld(const float* part, float* out, int32_t segments, int64_t rows, int32_t cols, int64_t ld,
+                    int32_t accumulate, float* tmp, int64_t tmp_floats, void* stream);
 
 /* first stage only: out[ceil(rows/rps)][cols]; insar_bn_finalize folds the remaining rows itself. */
 int insar_colsum_partial(const float* part, float* out, int64_t rows, int32_t cols, int32_t rps,
@@ -509,6 +521,9 @@ int insar_adam_step_dev(const int64_t* table, const int32_t* chunks, int32_t nch
 
 /* ---- small helpers ---------------------------------------------------------------------------- */
 int insar_scale_f32(float* p, int64_t n, float s, void* stream);
+/* out[i] = x[i] * *scale, the factor in DEVICE memory: backward of the loss entry points (criterion(...).backward() at :345
+ * hands d loss as a device scalar; no host read-back, no framework kernel). out and x 16-byte aligned. */
+int insar_mul_dev_f32(float* out, const float* x, int64_t n, const float* scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -113,6 +113,8 @@ _SIGNATURES = {
     "insar_wgrad_tile_pair": [_I, _I, _I],
     "insar_wgrad_conv3_tile": [_AP, _I],
     "insar_wgrad_conv3": [_AP, _AP, _P, _I, _P],
+    "insar_wgrad_conv3x_tile": [_AP, _I],
+    "insar_wgrad_conv3x": [_AP, _AP, _P, _I, _P],
     "insar_wgrad_reduce": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "insar_wgrad_fold": [_P, _P, _L, _I, _I, _P],
     "insar_pixel_table": [_P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -123,6 +125,7 @@ _SIGNATURES = {
     "insar_conv3x3_small_wgrad_fused_ok": [_P, _P],
     "insar_conv3x3_small_wgrad_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "insar_colsum": [_P, _P, _I, _L, _I, _I, _P, _L, _P],
+    "insar_colsum_ld": [_P, _P, _I, _L, _I, _L, _I, _P, _L, _P],
     "insar_colsum_partial": [_P, _P, _L, _I, _I, _P],
     "insar_bn_finalize": [C.POINTER(InsarBnFinalize), _P],
     "insar_bn_relu_apply": [_AP, _P, _P, _P, _AP, _I, _P],
@@ -162,6 +165,7 @@ _SIGNATURES = {
     "insar_confusion": [_P, _P, _I, _I, _L, _L, _P, _P],
     "insar_adam_step": [_P, _P, _I, _I, _F, _F, _F, _F, _F, _F, _F, _P],
     "insar_scale_f32": [_P, _L, _F, _P],
+    "insar_mul_dev_f32": [_P, _P, _L, _P, _P],
     "insar_adam_step_dev": [_P, _P, _I, _I, _F, C.c_double, C.c_double, _F, _P, _F, _P],
     "insar_pixel_table_taps": [_P, _L, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "insar_conv7x7s2_fwd_rows": [_I, _I],
@@ -218,7 +222,7 @@ def load():
     return lib
 
 
-_COUNT_ONLY = {"insar_tune_get", "insar_igemm_num_mtiles", "insar_igemm_tile_rows", "insar_igemm_tile_cols", "insar_igemm_tile_cols_dt", "insar_wgrad_tile", "insar_wgrad_tile_pair", "insar_wgrad_conv3_tile", "insar_conv3x3_flat_ok", "insar_conv3x3_flat_rows_ok", "insar_conv3x3_flat_rows_dil_ok", "insar_conv3x3_flat_num_mtiles", "insar_conv3x3_flat_stat_rows", "insar_conv3x3_c64_ok", "insar_conv3x3_c64_rows", "insar_conv3x3_c64_geometry", "insar_conv3x3_small_wgrad_blocks", "insar_conv3x3_small_wgrad_fused_ok", "insar_conv3x3_small_fwd_rows", "insar_conv1x1_out_bwd_blocks",
+_COUNT_ONLY = {"insar_tune_get", "insar_igemm_num_mtiles", "insar_igemm_tile_rows", "insar_igemm_tile_cols", "insar_igemm_tile_cols_dt", "insar_wgrad_tile", "insar_wgrad_tile_pair", "insar_wgrad_conv3_tile", "insar_wgrad_conv3x_tile", "insar_conv3x3_flat_ok", "insar_conv3x3_flat_rows_ok", "insar_conv3x3_flat_rows_dil_ok", "insar_conv3x3_flat_num_mtiles", "insar_conv3x3_flat_stat_rows", "insar_conv3x3_c64_ok", "insar_conv3x3_c64_rows", "insar_conv3x3_c64_geometry", "insar_conv3x3_small_wgrad_blocks", "insar_conv3x3_small_wgrad_fused_ok", "insar_conv3x3_small_fwd_rows", "insar_conv1x1_out_bwd_blocks",
                "insar_ce_blocks", "insar_conv7x7s2_fwd_rows", "insar_conv7x7s2_wgrad_blocks"}
 
 

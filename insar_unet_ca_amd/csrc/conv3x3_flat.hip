@@ -678,6 +678,9 @@ static int flat_impl(const InsarAct* x, const InsarAct* y, const void* w, int32_
   if (flip & 8) {       // row tiles (bf16, ping-pong loop)
     a.dil = ((flip >> 8) & 15) ? ((flip >> 8) & 15) : 1;
     if (!flat_rows_geometry(*x, a.dil)) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: row tiles need bf16, W a power of two in 16..256, H a multiple of 256 / W and 256 / W * (W + 2 * dilation) <= 320 (got %d x %d, dilation %d)", x->H, x->W, a.dil);
+    // the channel conditions insar_conv3x3_flat_rows_ok / _dil_ok promise, re-checked for a direct caller of the C ABI
+    if (x->c_len % 64 || y->c_len % 64) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: row tiles need K and N multiples of 64 (got %d, %d)", x->c_len, y->c_len);
+    if (flip & 4) INSAR_FAIL(INSAR_E_ARG, "insar_conv3x3_flat: row tiles (flip bit 3) have no persistent form (flip bit 2)");
     a.num_mtiles = (int)(((long long)x->B * x->H * x->W) / FL_BM);
     a.lw = 0;
     while ((1 << a.lw) < x->W) ++a.lw;

@@ -296,7 +296,7 @@ extern "C" int insar_weight_prep_pair_batch(const int64_t* jobs, int32_t njobs, 
 // grid = (col blocks of 64, row splits, segments); block = 64 cols x 4 row lanes.
 // ---------------------------------------------------------------------------------------------
 __global__ void colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t rows,
-                              int cols, int rows_per_split, int accumulate, int64_t out_split_stride) {
+                              int cols, int rows_per_split, int accumulate, int64_t out_split_stride, int64_t ld) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int lane_r = threadIdx.x >> 6;
@@ -305,8 +305,8 @@ __global__ void colsum_kernel(const float* __restrict__ part, float* __restrict_
   int64_t r1 = r0 + rows_per_split; if (r1 > rows) r1 = rows;
   float acc = 0.f;
   if (c < cols) {
-    const float* p = part + ((int64_t)seg * rows) * cols + c;
-    for (int64_t r = r0 + lane_r; r < r1; r += 4) acc += p[r * cols];
+    const float* p = part + ((int64_t)seg * rows) * ld + c;
+    for (int64_t r = r0 + lane_r; r < r1; r += 4) acc += p[r * ld];
   }
   red[lane_r][threadIdx.x & 63] = acc;
   __syncthreads();
@@ -318,34 +318,45 @@ __global__ void colsum_kernel(const float* __restrict__ part, float* __restrict_
   }
 }
 
-// Two-stage when there are many rows: stage 1 writes [nsplit][segments][cols] into `tmp`
-// (caller-provided, may be null when rows <= 256), stage 2 folds the splits.
-extern "C" int insar_colsum(const float* part, float* out, int32_t segments, int64_t rows, int32_t cols,
-                            int32_t accumulate, float* tmp, int64_t tmp_floats, void* stream) {
-  if (!part || !out) INSAR_FAIL(INSAR_E_ARG, "insar_colsum: null pointer");
-  if (segments < 1 || rows < 1 || cols < 1) INSAR_FAIL(INSAR_E_SHAPE, "insar_colsum: bad shape");
+static int colsum_impl(const char* who, const float* part, float* out, int32_t segments, int64_t rows, int32_t cols, int64_t ld,
+                       int32_t accumulate, float* tmp, int64_t tmp_floats, void* stream) {
+  if (!part || !out) INSAR_FAIL(INSAR_E_ARG, "%s: null pointer", who);
+  if (segments < 1 || rows < 1 || cols < 1 || ld < cols) INSAR_FAIL(INSAR_E_SHAPE, "%s: bad shape", who);
   hipStream_t s = (hipStream_t)stream;
   const int cb = (cols + 63) / 64;
   if (rows <= 256 || !tmp) {
     hipLaunchKernelGGL(colsum_kernel, dim3(cb, 1, segments), dim3(256), 0, s, part, out, rows, cols,
-                       (int)(rows > 0x7fffffff ? 0x7fffffff : rows), accumulate, (int64_t)0);
-    INSAR_CHECK_LAUNCH("insar_colsum");
+                       (int)(rows > 0x7fffffff ? 0x7fffffff : rows), accumulate, (int64_t)0, ld);
+    INSAR_CHECK_LAUNCH(who);
     return INSAR_OK;
   }
   int rps = 128;
   int64_t nsplit = (rows + rps - 1) / rps;
   while (nsplit > 512) { rps *= 2; nsplit = (rows + rps - 1) / rps; }
   if (nsplit * segments * (int64_t)cols > tmp_floats)
-    INSAR_FAIL(INSAR_E_WS, "insar_colsum: tmp too small (%lld < %lld floats)", (long long)tmp_floats,
+    INSAR_FAIL(INSAR_E_WS, "%s: tmp too small (%lld < %lld floats)", who, (long long)tmp_floats,
                (long long)(nsplit * segments * (int64_t)cols));
   hipLaunchKernelGGL(colsum_kernel, dim3(cb, (int)nsplit, segments), dim3(256), 0, s, part, tmp, rows, cols, rps,
-                     0, (int64_t)segments * cols);
+                     0, (int64_t)segments * cols, ld);
   // stage 2: treat tmp as [1 segment][nsplit rows][segments*cols]
   const int cols2 = segments * cols;
   hipLaunchKernelGGL(colsum_kernel, dim3((cols2 + 63) / 64, 1, 1), dim3(256), 0, s, tmp, out, nsplit, cols2,
-                     (int)nsplit, accumulate, (int64_t)0);
-  INSAR_CHECK_LAUNCH("insar_colsum");
+                     (int)nsplit, accumulate, (int64_t)0, (int64_t)cols2);
+  INSAR_CHECK_LAUNCH(who);
   return INSAR_OK;
+}
+
+// Two-stage when there are many rows: stage 1 writes [nsplit][segments][cols] into `tmp`
+// (caller-provided, may be null when rows <= 256), stage 2 folds the splits.
+extern "C" int insar_colsum(const float* part, float* out, int32_t segments, int64_t rows, int32_t cols,
+                            int32_t accumulate, float* tmp, int64_t tmp_floats, void* stream) {
+  return colsum_impl("insar_colsum", part, out, segments, rows, cols, cols, accumulate, tmp, tmp_floats, stream);
+}
+// The first `cols` columns of rows that are `ld` floats apart (a gradient summed straight into its place in the flat
+// gradient buffer: the transposed convs' bias, outc's weight and bias; no staging tensor, no copy).
+extern "C" int insar_colsum_ld(const float* part, float* out, int32_t segments, int64_t rows, int32_t cols, int64_t ld,
+                               int32_t accumulate, float* tmp, int64_t tmp_floats, void* stream) {
+  return colsum_impl("insar_colsum_ld", part, out, segments, rows, cols, ld, accumulate, tmp, tmp_floats, stream);
 }
 
 // First stage only: out[split][c] = sum of rows [split*rps, (split+1)*rps) of part[rows][cols]; the consumer
@@ -356,7 +367,7 @@ extern "C" int insar_colsum_partial(const float* part, float* out, int64_t rows,
   const int64_t nsplit = (rows + rps - 1) / rps;
   if (nsplit > 65535) INSAR_FAIL(INSAR_E_SHAPE, "insar_colsum_partial: too many splits");
   hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, (unsigned)nsplit, 1), dim3(256), 0, (hipStream_t)stream, part, out,
-                     rows, cols, rps, 0, (int64_t)cols);
+                     rows, cols, rps, 0, (int64_t)cols, (int64_t)cols);
   INSAR_CHECK_LAUNCH("insar_colsum_partial");
   return INSAR_OK;
 }
@@ -2033,5 +2044,26 @@ extern "C" int insar_scale_f32(float* p, int64_t n, float s, void* stream) {
   if (!p) INSAR_FAIL(INSAR_E_ARG, "insar_scale_f32: null pointer");
   hipLaunchKernelGGL(scale_kernel, dim3(insar_grid_cap((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, n, s);
   INSAR_CHECK_LAUNCH("insar_scale_f32");
+  return INSAR_OK;
+}
+
+// out[i] = x[i] * *scale with the factor read from device memory: the loss functions' backward (d loss / d logits times the
+// incoming gradient of the scalar loss, which autograd hands over as a device tensor) without a host read-back.
+__global__ void mul_dev_kernel(float* __restrict__ out, const float* __restrict__ x, int64_t n, const float* __restrict__ scale) {
+  const float s = *scale;
+  const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 v = ((const float4*)x)[i];
+    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+    ((float4*)out)[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[(n4 << 2) + threadIdx.x] = x[(n4 << 2) + threadIdx.x] * s;
+}
+extern "C" int insar_mul_dev_f32(float* out, const float* x, int64_t n, const float* scale, void* stream) {
+  if (!out || !x || !scale) INSAR_FAIL(INSAR_E_ARG, "insar_mul_dev_f32: null pointer");
+  if (!insar_aligned16(out) || !insar_aligned16(x)) INSAR_FAIL(INSAR_E_ALIGN, "insar_mul_dev_f32: buffers not 16-byte aligned");
+  if (n < 1) return INSAR_OK;
+  hipLaunchKernelGGL(mul_dev_kernel, dim3(insar_grid_cap((n / 4 + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, out, x, n, scale);
+  INSAR_CHECK_LAUNCH("insar_mul_dev_f32");
   return INSAR_OK;
 }

@@ -254,6 +254,9 @@ class DevicePrefetcher:
             self._dev[slot] = (torch.empty(x.shape, dtype=x.dtype, device=self.device),
                                torch.empty(y.shape, dtype=y.dtype, device=self.device))
             self._pin[slot] = None
+            # the caching allocator may hand back a block whose last use on the compute stream is still queued (first use
+            # of a slot, or a re-allocation for the last, smaller batch): the first copy into it waits for that stream
+            self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
         compact = False
         if self.compact_masks and y.dtype == torch.int64 and y.device.type == "cpu" and y.numel() > 0:
             # numpy, not torch: a torch reduction wakes the whole intra-op thread pool (128 threads on a 16-core GPU box:
@@ -264,6 +267,7 @@ class DevicePrefetcher:
             if self._pin_u8[slot] is None or self._pin_u8[slot].shape != y.shape:
                 self._pin_u8[slot] = torch.empty(y.shape, dtype=torch.uint8).pin_memory()
                 self._dev_u8[slot] = torch.empty(y.shape, dtype=torch.uint8, device=self.device)
+                self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
             if self._ready[slot] is not None:
                 self._ready[slot].synchronize()       # the previous copy out of this pinned buffer is done
             np.copyto(self._pin_u8[slot].numpy(), yn, casting="unsafe")     # int64 -> uint8 on the host, exact for 0..255

@@ -733,7 +733,7 @@ class DeepLabPlan(tape.PlanTape):
         if dlogits.dtype != torch.float32 or not dlogits.is_contiguous():
             dlogits = dlogits.float().contiguous()
         self.sink.select()
-        if not self._tape_allowed(self.training, on_bucket is None and not self.external_mask):
+        if not self._tape_allowed(self.training, on_bucket is None and not self.external_mask and not self.weightset.stale()):
             return self._backward_eager(dlogits, on_bucket)
         xp = self.x_in.data_ptr()
         out, replayed = self._run(self._tape_key("b"), lambda: self._backward_eager(dlogits, None),

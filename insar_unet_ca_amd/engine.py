@@ -126,13 +126,31 @@ class Ctx:
             self._side_busy = False
 
     def colsum(self, part: torch.Tensor, out: torch.Tensor, segments: int, rows: int, cols: int,
-               accumulate: bool = False) -> None:
+               accumulate: bool = False, ld: Optional[int] = None, part_off: int = 0) -> None:
+        """out[s][c] (+)= sum_r part[s][r][c]; ld: row stride of `part` when only its first `cols` columns (from float
+        offset `part_off`) are wanted — a gradient summed straight into its view of the flat gradient buffer."""
         s = _lib.stream_ptr()
         tmp = self._colsum_tmp.get(s)
         need = ((rows + 127) // 128) * segments * cols if rows > 256 else 0
         if tmp is None or need > tmp.numel():
             tmp = self._colsum_tmp[s] = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=self.device)
-        call("insar_colsum", ptr(part), ptr(out), segments, rows, cols, int(accumulate), ptr(tmp), tmp.numel(), s)
+        if ld is None:
+            call("insar_colsum", ptr(part), ptr(out), segments, rows, cols, int(accumulate), ptr(tmp), tmp.numel(), s)
+        else:
+            call("insar_colsum_ld", ptr(part) + 4 * part_off, ptr(out), segments, rows, cols, ld, int(accumulate), ptr(tmp), tmp.numel(), s)
+
+    def colsum_into_grads(self, part: torch.Tensor, rows: int, views: List[torch.Tensor]) -> None:
+        """Fold part[rows][sum of the views' sizes] into consecutive parameter-gradient views (outc's weight and bias): one
+        launch when the views are adjacent in the flat buffer, one per view otherwise; no staging tensor, no copy."""
+        total = sum(v.numel() for v in views)
+        adjacent = all(views[i + 1].data_ptr() == views[i].data_ptr() + 4 * views[i].numel() for i in range(len(views) - 1))
+        if adjacent:
+            self.colsum(part, views[0], 1, rows, total)
+            return
+        off = 0
+        for v in views:
+            self.colsum(part, v, 1, rows, v.numel(), ld=total, part_off=off)
+            off += v.numel()
 
     def wgrad_part(self, floats: int) -> torch.Tensor:
         if self._wgrad_part is None or self._wgrad_part.numel() < floats:
@@ -227,6 +245,8 @@ class GemmWeight:
 
     def _get(self, which: str) -> torch.Tensor:
         if self._key[which] != self.key():
+            if tape.REC is not None:       # a per-weight re-layout depends on state the tape does not see: stay eager
+                tape.REC.bad("weight re-layout inside a recording")
             T, N, K, st, sn, sk = self._spec[which]
             call("insar_weight_prep", ptr(self.master()), ptr(self._buf[which]), self.ctx.code, T, N, K, st, sn, sk,
                  _lib.stream_ptr())
@@ -262,9 +282,17 @@ class WeightSet:
             self._by_stage = [WeightSet(self.ctx, b) if b else None for b in buckets]
         return self._by_stage
 
+    def stale(self) -> bool:
+        return any(w._key["fwd"] != w.key() or w._key["dgrad"] != w.key() for w in self.weights)
+
     def refresh(self) -> None:
-        stale = [w for w in self.weights if w._key["fwd"] != w.key() or w._key["dgrad"] != w.key()]
-        if not stale:
+        """Re-lay the GEMM copies if any master moved. On a launch tape this is ONE live op (tape.tape_live): the check
+        runs on every replay exactly as it does here, and nothing it launches is baked into the tape — a recording made
+        while no weight was stale (several forwards before the first optimizer step) must not lose the re-layout."""
+        tape.tape_live(self._refresh_now)
+
+    def _refresh_now(self) -> None:
+        if not self.stale():
             return
         ptrs = tuple(w.param.data_ptr() for w in self.weights)
         if self._jobs is None or ptrs != self._ptrs:
@@ -280,11 +308,8 @@ class WeightSet:
             self._jobs = torch.tensor(rows, dtype=torch.int64).to(self.ctx.device)
             self._ptrs, self._total = ptrs, tile0
         call("insar_weight_prep_pair_batch", ptr(self._jobs), self._jobs.shape[0], self._total, _lib.stream_ptr())
-
-        def mark():         # (on a launch tape too: code that runs eagerly afterwards must find the copies current)
-            for w in self.weights:
-                w._key["fwd"] = w._key["dgrad"] = w.key()
-        tape_py(mark)
+        for w in self.weights:
+            w._key["fwd"] = w._key["dgrad"] = w.key()
 
 
 class KernelTimer:
@@ -337,6 +362,7 @@ WGRAD_FILL_DL = float(os.environ.get("INSAR_WGRAD_FILL_DL", "0.5"))  # ... and f
 WGRAD_FILL_ALONE = float(os.environ.get("INSAR_WGRAD_FILL_ALONE", "1.0"))   # ... and when it has the GPU to itself
 WGRAD_FILL = float(os.environ.get("INSAR_WGRAD_FILL", "0.6"))     # share of the work-group slots a side-stream weight gradient aims at (0.5 until the row tiles made the dgrad chain faster: re-swept, 0.55-0.65 with 0.7 for the transposed convs is 0.09 ms better, profiles/r03_row_tiles.txt)
 WGRAD_ROWS = os.environ.get("INSAR_WGRAD_ROWS", "1") != "0"      # diagnostic: 0 = per-tap weight-gradient kernel everywhere
+WGRAD_X = os.environ.get("INSAR_WGRAD_X", "1") != "0"            # diagnostic: 0 = the 128 x 128 row-of-taps kernel (wgrad3.hip) also where the 256 x 128 six-phase kernel (wgrad3x.hip) applies; slabs bit for bit equal at equal nsplit
 FLAT_PP = int(os.environ.get("INSAR_FLAT_PP", "1"))               # flat 3x3 kernel: ping-pong tap steps (0 = plain loop; bitwise equal)
 FLAT_PERSIST = int(os.environ.get("INSAR_FLAT_PERSIST", "2"))     # flat 3x3 kernel: one work-group per CU walking its tiles (bitwise equal): 1 = forward launches, 2 = all (default since round 3: with the BatchNorm-backward sums carried over a work-group's tiles the input-gradient launches gain too, same-box 7.55 -> 7.49 ms/step), 0 = off
 IGEMM_PP = int(os.environ.get("INSAR_IGEMM_PP", "1"))            # 256 x 256 tiles: ping-pong K loop (0 = the plain two-slab loop; bitwise equal)
@@ -926,8 +952,12 @@ def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
     B, H, W = x.B, x.H, x.W
     cin, cout = x.c_len, dy.c_len
     pair = call("insar_wgrad_conv3_tile", x.ref, cout) if WGRAD_ROWS else 0
-    if pair:
-        # three taps of a kernel row per work-group (csrc/wgrad3.hip): a third of the operand staging
+    pairx = call("insar_wgrad_conv3x_tile", x.ref, cout) if (WGRAD_ROWS and WGRAD_X) else 0
+    if pair or pairx:
+        # three taps of a kernel row per work-group (csrc/wgrad3.hip): a third of the operand staging; where one side has
+        # 256 channels and the other 128, the 256 x 128 tile kernel with the six-phase K loop (csrc/wgrad3x.hip)
+        entry = "insar_wgrad_conv3x" if pairx else "insar_wgrad_conv3"
+        pair = pairx or pair
         tm, tn = pair >> 16, pair & 0xffff
         tiles = 3 * (cin // tm) * (cout // tn)
         # Beside the dgrad chain (side stream) the weight gradient should fill about HALF the work-group slots: the
@@ -943,14 +973,17 @@ def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
             nsplit = min(nsplit, max(1, WGRAD_GRID_CAP // tiles))
         part = ctx.wgrad_part(nsplit * 9 * cout * cin)
         if PROFILER is not None:
-            tag = "wgrad3_kernel<%s, %d, %d, %d>" % ("float" if ctx.code == _lib.F32 else "bf16_t", tm, tn,
-                                                     8 if tm == 128 and tn == 128 else 4)
+            if pairx:
+                tag = "wgrad3x_kernel<%d, %d>" % (tm, tn)
+            else:
+                tag = "wgrad3_kernel<%s, %d, %d, %d>" % ("float" if ctx.code == _lib.F32 else "bf16_t", tm, tn,
+                                                         8 if tm == 128 and tn == 128 else 4)
             # algorithmic bytes: both operands read once, the split-K slabs written once
             nbytes = ctx.esize * B * H * W * (cin + cout) + 4.0 * nsplit * 9 * cout * cin
             PROFILER.run(tag, 2.0 * B * H * W * cin * cout * 9,
-                         lambda: call("insar_wgrad_conv3", x.ref, dy.ref, ptr(part), nsplit, _lib.stream_ptr()), nbytes)
+                         lambda: call(entry, x.ref, dy.ref, ptr(part), nsplit, _lib.stream_ptr()), nbytes)
         else:
-            call("insar_wgrad_conv3", x.ref, dy.ref, ptr(part), nsplit, _lib.stream_ptr())
+            call(entry, x.ref, dy.ref, ptr(part), nsplit, _lib.stream_ptr())
         ctx.wgrad_finish(part, grad, nsplit, 9, cout, cin, 0)
         return
     tabx = ctx.pixel_table(B, H, W, 1, H, W, W + 3)      # taps move on x: tail = first interior pixel
@@ -1094,9 +1127,7 @@ class UpPlan:
                 if self.mod.bias is not None:     # dbias = sum over pixels of dout (mask-free row reduction)
                     call("insar_bnrelu_bwd_reduce", dout.ref, dout.ref, ptr(ctx.const(0.0, self.cout)),
                          ptr(ctx.const(1.0, self.cout)), ptr(self.bias_part), 0, self.bias_rpp, _lib.stream_ptr())
-                    ctx.colsum(self.bias_part, self.bias_sum, 1, self.bias_rows, 2 * self.cout)
-                    dst_b, src_b = sink.view(self.mod.bias), self.bias_sum[0]
-                    tape_py(lambda: dst_b.copy_(src_b))
+                    ctx.colsum(self.bias_part, sink.view(self.mod.bias), 1, self.bias_rows, self.cout, ld=2 * self.cout)
                 part = ctx.wgrad_part(nsplit * 4 * self.cout * self.cin)
                 d = InsarWgrad()
                 d.x, d.dy = x.desc, dout.desc
@@ -1159,13 +1190,7 @@ class OutConvPlan:
         """dx = None: only outc's parameter gradients (side stream); the unit below recomputes its incoming gradient
         from dlogits (ConvBN.backward, outc_grad)."""
         def fold():
-            self.ctx.colsum(self.part, self.folded, 1, self.nb, self.cols)
-            kc = self.K * self.cin
-            dst_w, src_w = sink.view(self.mod.weight).view(-1), self.folded[:kc]
-            tape_py(lambda: dst_w.copy_(src_w))
-            if self.mod.bias is not None:
-                dst_b, src_b = sink.view(self.mod.bias), self.folded[kc:]
-                tape_py(lambda: dst_b.copy_(src_b))
+            self.ctx.colsum_into_grads(self.part, self.nb, self._grad_views(sink))
 
         if dx is None and self.reduce_rows:
             # the parameter-gradient partials come out of the unit's BatchNorm-backward reduce pass (same read of y): only
@@ -1209,13 +1234,13 @@ class OutConvPlan:
         if not self.reduce_rows:
             return
         with self.ctx.side_stream():
-            self.ctx.colsum(self.part_red, self.folded, 1, self.reduce_rows, self.cols)
-            kc = self.K * self.cin
-            dst_w, src_w = sink.view(self.mod.weight).view(-1), self.folded[:kc]
-            tape_py(lambda: dst_w.copy_(src_w))
-            if self.mod.bias is not None:
-                dst_b, src_b = sink.view(self.mod.bias), self.folded[kc:]
-                tape_py(lambda: dst_b.copy_(src_b))
+            self.ctx.colsum_into_grads(self.part_red, self.reduce_rows, self._grad_views(sink))
+
+    def _grad_views(self, sink: GradSink) -> List[torch.Tensor]:
+        """outc's weight (and bias) gradient views; a bias-free outc still folds K trailing columns (into scratch)."""
+        if self.mod.bias is not None:
+            return [sink.view(self.mod.weight), sink.view(self.mod.bias)]
+        return [sink.view(self.mod.weight), self.folded[self.K * self.cin:]]
 
     def virtual_grad_ok(self) -> bool:
         ch = 16 // self.ctx.esize
@@ -1362,7 +1387,9 @@ class UNetPlan(tape.PlanTape):
         if dlogits.dtype != torch.float32 or not dlogits.is_contiguous():
             dlogits = dlogits.float().contiguous()
         self.sink.select()
-        if not (self._tape_allowed(self.training, on_bucket is None) and self.outc.virtual_grad_ok()):
+        # (a master that moved between forward and backward — an optimizer step in between — is re-laid per weight by the
+        # ordinary code; a tape would keep the copies the forward used)
+        if not (self._tape_allowed(self.training, on_bucket is None and not self.weightset.stale()) and self.outc.virtual_grad_ok()):
             return self._backward_eager(dlogits, on_bucket)
         out, replayed = self._run(self._tape_key("b"), lambda: self._backward_eager(dlogits, None),
                                   {"dlogits": dlogits.data_ptr()}, {dlogits.data_ptr(): "dlogits"})

@@ -35,6 +35,19 @@ def _prep(logits: torch.Tensor, target: torch.Tensor, who: str):
     return lg, tg, B, K, HW
 
 
+def _scale_by(dl: torch.Tensor, g: torch.Tensor, in_dtype) -> torch.Tensor:
+    """d loss / d logits times the incoming gradient of the scalar loss, on the HIP path (insar_mul_dev_f32: the factor is
+    read from device memory; dl itself is kept for a second backward)."""
+    if g.numel() != 1 or not g.is_cuda:
+        raise _lib.InsarError("loss backward: the incoming gradient must be a device scalar")
+    gs = g.detach()
+    if gs.dtype != torch.float32:
+        gs = gs.float()
+    out = torch.empty_like(dl)
+    call("insar_mul_dev_f32", ptr(out), ptr(dl), dl.numel(), ptr(gs), _lib.stream_ptr())
+    return out if in_dtype == torch.float32 else out.to(in_dtype)
+
+
 class _CEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, ignore_index):
@@ -50,7 +63,7 @@ class _CEFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return (ctx.dl * g).to(ctx.in_dtype), None, None
+        return _scale_by(ctx.dl, g, ctx.in_dtype), None, None
 
 
 class _DiceFn(torch.autograd.Function):
@@ -69,7 +82,7 @@ class _DiceFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return (ctx.dl * g).to(ctx.in_dtype), None, None, None
+        return _scale_by(ctx.dl, g, ctx.in_dtype), None, None, None
 
 
 class _DiceCEFn(torch.autograd.Function):
@@ -91,7 +104,7 @@ class _DiceCEFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return (ctx.dl * g).to(ctx.in_dtype), None, None, None, None, None
+        return _scale_by(ctx.dl, g, ctx.in_dtype), None, None, None, None, None
 
 
 class CrossEntropyLoss(nn.Module):

@@ -205,12 +205,14 @@ class Adam(torch.optim.Adam):
         f = self._fast
         if f is None or len(self.param_groups) != 1:
             return False
-        params, grads, steps, table, chunk_t, nchunks = f
+        params, grads, steps, table, chunk_t, nchunks, ptrs = f
         group = self.param_groups[0]
         if len(group["params"]) != len(params):
             return False
-        for p, q, g in zip(group["params"], params, grads):
-            if p is not q or p.grad is not g:
+        for p, q, g, a in zip(group["params"], params, grads, ptrs):
+            # same Parameter, same gradient tensor AND the same parameter storage: `p.data = ...` / load_state_dict(assign=True)
+            # keep the Parameter object but move its memory, and the table holds raw addresses
+            if p is not q or p.grad is not g or p.data_ptr() != a:
                 return False
         b1, b2 = group["betas"]
         if self._dev_state is not None:
@@ -257,7 +259,7 @@ class Adam(torch.optim.Adam):
                      float(group["eps"]), ptr(self._dev_state), float(self.grad_scale), _lib.stream_ptr())
                 torch._C._increment_version(params)
                 if len(self.param_groups) == 1:
-                    self._fast = (list(params), list(grads), list(steps), table, chunk_t, nchunks)
+                    self._fast = (list(params), list(grads), list(steps), table, chunk_t, nchunks, [p.data_ptr() for p in params])
                 continue
             by_step = {}
             for p, g, m, v, st in zip(params, grads, exp_avgs, exp_avg_sqs, steps):
@@ -276,7 +278,7 @@ class Adam(torch.optim.Adam):
                      float(group["eps"]), bc1, bc2_sqrt, float(self.grad_scale), _lib.stream_ptr())
                 torch._C._increment_version([p for p, _, _, _ in tensors])
             if len(self.param_groups) == 1 and len(by_step) == 1 and len(params) == len(group["params"]):
-                self._fast = (list(params), list(grads), list(steps), table, chunk_t, nchunks)
+                self._fast = (list(params), list(grads), list(steps), table, chunk_t, nchunks, [p.data_ptr() for p in params])
         if self._dev_state is not None:
             self._dev_pending += 1
         return loss

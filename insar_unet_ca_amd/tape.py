@@ -120,12 +120,30 @@ def tape_py(fn: Callable[[], None]) -> None:
         REC.op("py", fn)
 
 
+def tape_live(fn: Callable[[], None]) -> None:
+    """Run `fn` — plan code whose launches depend on state a tape cannot see (WeightSet.refresh: are the GEMM copies of the
+    weights stale?) — with recording suspended, and put `fn` ITSELF on the tape: a replay calls it at the same point of the
+    launch sequence, on whatever stream is current there, and it decides afresh every time."""
+    global REC
+    rec = REC
+    if rec is None:
+        fn()
+        return
+    REC, _lib._TAPE = None, None
+    try:
+        fn()
+    finally:
+        REC, _lib._TAPE = rec, rec.entries
+    rec.op("py", fn)
+
+
 class PlanTape:
     """Mixin of engine.UNetPlan / deeplab.DeepLabPlan: `forward` / `backward` dispatch between the ordinary code
     (`_forward_eager`, `_backward_eager`) and the tape of that code."""
 
     def _tape_setup(self) -> None:
         self._tapes: Dict[tuple, dict] = {}
+        self._tape_params = list(self.net.parameters())
 
     # what must not change under a tape (cheap to evaluate per call)
     def _tape_key(self, which: str) -> tuple:
@@ -133,10 +151,21 @@ class PlanTape:
         bn = tuple((m.momentum, m.eps) for m in self.bn_modules)
         # module-level switches the launch code reads at call time (tests flip them with monkeypatch): part of the key too
         flags = (engine.BSTAT_FUSE, engine.BSTAT_C64, engine.COEF_SIMPLE, engine.COEF_FUSE, engine.SPLIT_COEF, engine.POOL_FUSE,
-                 engine.OUTC_FUSE, engine.OUTC_WGRAD_FUSE, engine.PREP_SIDE, engine.SMALL_WGRAD_MAIN, engine.SMALL_WGRAD_FUSE, engine.WGRAD_LATE, engine.WGRAD_ROWS, engine.FLAT_PP,
+                 engine.OUTC_FUSE, engine.OUTC_WGRAD_FUSE, engine.PREP_SIDE, engine.SMALL_WGRAD_MAIN, engine.SMALL_WGRAD_FUSE, engine.WGRAD_LATE, engine.WGRAD_ROWS, engine.WGRAD_X, engine.FLAT_PP,
                  engine.FLAT_PERSIST, engine.FLAT_ROWS, engine.IGEMM_PP, engine.WGRAD_FILL, engine.WGRAD_FILL_T, engine.WGRAD_FILL_DL, engine.WGRAD_GRID_CAP,
                  getattr(sys.modules.get(__package__ + ".deeplab"), "GATE_FUSE", None), getattr(sys.modules.get(__package__ + ".deeplab"), "GATE_STATS", None))
         return (which, self.sink.active if which == "b" else 0, hash(bn), hash(flags))
+
+    def _tape_fingerprint(self) -> int:
+        """Storage addresses a tape bakes into its prebuilt arguments: every parameter of the plan and every BatchNorm buffer.
+        The ordinary code re-reads them per call (p.data = ..., load_state_dict(assign=True), module.to(), a swapped
+        running_mean all work there); a tape whose fingerprint no longer matches is dropped and recorded again."""
+        ptrs = [p.data_ptr() for p in self._tape_params]
+        for m in self.bn_modules:
+            ptrs.append(m.running_mean.data_ptr() if m.running_mean is not None else 0)
+            ptrs.append(m.running_var.data_ptr() if m.running_var is not None else 0)
+            ptrs.append(m.num_batches_tracked.data_ptr() if m.num_batches_tracked is not None else 0)
+        return hash(tuple(ptrs))
 
     def _tape_allowed(self, training: bool, extra_ok: bool = True) -> bool:
         from . import engine
@@ -146,8 +175,13 @@ class PlanTape:
     def _run(self, key: tuple, eager: Callable, slots: Dict[str, int], dyn_ptrs: Dict[int, str], dyn_after=None):
         """eager(): the ordinary code, returns its result. Returns (result or None, replayed?). dyn_ptrs: boundary pointers
         known before the call (pointer -> slot name); dyn_after(result): those only known afterwards (the logits tensor)."""
-        st = self._tapes.setdefault(key, {"state": 0, "tape": None, "calls": 0})
+        st = self._tapes.setdefault(key, {"state": 0, "tape": None, "calls": 0, "fp": None})
         st["calls"] += 1
+        fp = self._tape_fingerprint()
+        if st["fp"] != fp:                        # storage moved under the tape (or first call): start over
+            if st["state"] not in (0, -1):
+                st["moved"] = st.get("moved", 0) + 1
+            st["state"], st["tape"], st["fp"] = (0 if st.get("moved", 0) < 8 else -1), None, fp
         if st["state"] == 3:
             if MODE == "verify" and st["calls"] % 16 == 0:
                 out, rec = self._record(eager, dyn_ptrs, dyn_after)
@@ -189,32 +223,37 @@ class PlanTape:
         ctx = self.ctx
         main = _lib.stream_ptr()
         side = ctx.side.cuda_stream
-        prev = None
-        for op in ops:
-            k = op[0]
-            if k == 0:
-                rc = op[1](*op[2], main)
-            elif k == 1:
-                rc = op[1](*op[2], side)
-            elif k == 2:
-                body = list(op[2])
-                for i, slot in op[4]:
-                    body[i] = slots[slot]
-                rc = op[1](*body, side if op[3] else main)
-            elif k == 3:
-                prev = ctx._side_enter()
-                continue
-            elif k == 4:
+        prev = None                               # torch's current stream while a side section is open
+        try:
+            for op in ops:
+                k = op[0]
+                if k == 0:
+                    rc = op[1](*op[2], main)
+                elif k == 1:
+                    rc = op[1](*op[2], side)
+                elif k == 2:
+                    body = list(op[2])
+                    for i, slot in op[4]:
+                        body[i] = slots[slot]
+                    rc = op[1](*body, side if op[3] else main)
+                elif k == 3:
+                    prev = ctx._side_enter()
+                    continue
+                elif k == 4:
+                    ctx._side_exit(prev)
+                    prev = None
+                    continue
+                elif k == 5:
+                    ctx.join_side()
+                    continue
+                else:
+                    op[1]()
+                    continue
+                if rc != 0:
+                    raise _lib.InsarError(f"{op[-1]} failed ({rc}) during tape replay: {_lib.load().insar_last_error().decode(errors='replace')}")
+        finally:
+            if prev is not None:                  # a launch failed inside a side section: restore the caller's stream
                 ctx._side_exit(prev)
-                continue
-            elif k == 5:
-                ctx.join_side()
-                continue
-            else:
-                op[1]()
-                continue
-            if rc != 0:
-                raise _lib.InsarError(f"{op[-1]} failed ({rc}) during tape replay: {_lib.load().insar_last_error().decode(errors='replace')}")
 
     def tape_report(self) -> Dict[tuple, str]:
         names = {0: "not yet", 1: "recording", 2: "recording", 3: "replaying", -1: "given up"}

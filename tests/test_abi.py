@@ -89,6 +89,11 @@ def test_tile_selection_queries_without_a_gpu():
     assert rows(256, 256, 64, 64, BF16) == (64, 64) and rows(64, 64, 512, 256, BF16) == (128, 128)
     assert rows(32, 32, 512, 512, BF16) == (128, 128) and rows(16, 16, 1024, 1024, F32) == (128, 128)
     assert rows(48, 80, 64, 64, BF16) == (0, 0) and rows(3, 16, 64, 64, BF16) == (0, 0)     # per-tap kernel there
+    # ... and its 256 x 128 / 128 x 256 six-phase variant: bf16, 256 channels on one side and 128 on the other
+    rowsx = lambda h, w, ci, co, dt: divmod(call("insar_wgrad_conv3x_tile", act(h, w, ci, dt), co), 1 << 16)
+    assert rowsx(64, 64, 512, 256, BF16) == (256, 128) and rowsx(16, 16, 1024, 1024, BF16) == (256, 128)
+    assert rowsx(64, 64, 128, 256, BF16) == (128, 256) and rowsx(128, 128, 256, 128, BF16) == (256, 128)
+    assert rowsx(128, 128, 128, 128, BF16) == (0, 0) and rowsx(64, 64, 512, 256, F32) == (0, 0) and rowsx(48, 80, 512, 256, BF16) == (0, 0)
     # statistics slab of the flat 3x3 kernel: one row per M tile; persistent work-groups (flip bit 2) with one N tile carry
     # the sums over their tiles: one row per work-group (= CUs, 256 when no device answers), unless the grid is smaller
     big, small = act(256, 256, 128, BF16), act(32, 32, 128, BF16)

@@ -323,3 +323,26 @@ def test_deeplab_checkpoint_loaders_follow_the_reference_call_site():
     net.load_backbone_state_dict(resnet)
     assert torch.allclose(net.backbone["conv1"].weight, resnet["conv1.weight"].mean(1, keepdim=True))
     assert torch.equal(net.model.backbone["layer3"][2].conv2.weight, resnet["layer3.2.conv2.weight"])
+
+
+def test_switch_table_is_read_off_the_source(monkeypatch):
+    """insar_unet_ca_amd.switches: every INSAR_* variable the package reads is known with its default; what the environment
+    sets differently (or what the package does not know) is reported — bench.py prints it and refuses a default run."""
+    import os
+    from insar_unet_ca_amd import switches
+    known = switches.declared([os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")])
+    for name, default in (("INSAR_WGRAD_FILL", "0.6"), ("INSAR_TAPE", "1"), ("INSAR_FLAT_PERSIST", "2"), ("INSAR_HIP_LIB", None),
+                          ("INSAR_GATE_FUSE", "1"), ("INSAR_ADAM_CHUNK", "8192"), ("INSAR_MAIN_PRIORITY", None)):
+        assert name in known and known[name] == default, (name, known.get(name))
+    for k in list(os.environ):
+        if k.startswith("INSAR_"):
+            monkeypatch.delenv(k)
+    assert switches.non_default() == {}
+    monkeypatch.setenv("INSAR_WGRAD_FILL", "0.6")            # the default, spelled out: not a change
+    monkeypatch.setenv("INSAR_TAPE", "0")
+    monkeypatch.setenv("INSAR_FLAT_ROWS", "0")
+    monkeypatch.setenv("INSAR_NO_SUCH_SWITCH", "1")
+    nd = switches.non_default()
+    assert set(nd) == {"INSAR_TAPE", "INSAR_FLAT_ROWS", "INSAR_NO_SUCH_SWITCH"}
+    assert nd["INSAR_TAPE"]["kernel_selecting"] is False and nd["INSAR_FLAT_ROWS"]["kernel_selecting"] is True
+    assert nd["INSAR_NO_SUCH_SWITCH"].get("unknown") is True

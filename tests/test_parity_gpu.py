@@ -194,6 +194,52 @@ def test_igemm_family_against_float64(dev, dtype, cin, cout, shape):
     assert max_rel(gwt, wv.grad) <= KERNEL_TOL * 5          # fp32 accumulation in both dtypes
 
 
+@pytest.mark.parametrize("cin,cout,shape,c_extra", [
+    (256, 128, (2, 256, 8, 64), 0),      # W = 64: a K step is one image row; 16 K steps
+    (256, 128, (1, 256, 4, 128), 64),    # two K steps per image row; x is a channel slice of a wider buffer
+    (512, 256, (2, 512, 32, 32), 0),     # two image rows per K step (W = 32), 2 x 2 tiles
+    (256, 256, (4, 256, 16, 16), 0),     # four image rows per K step (W = 16)
+    (128, 256, (2, 128, 16, 64), 0),     # 128 x 256 tiles (only Cout has 256)
+    (256, 128, (1, 256, 1, 64), 0),      # ONE K step in all
+    (256, 128, (1, 256, 2, 64), 0),      # two K steps
+])
+def test_wgrad_conv3x_against_float64_and_the_128_tile_kernel(dev, cin, cout, shape, c_extra):
+    """csrc/wgrad3x.hip (256 x 128 tiles, six-phase K loop, three-slot LDS ring with a counted wait): the weight gradient
+    against float64 on the kernel's own operands, and its split-K slabs BIT FOR BIT those of insar_wgrad_conv3 at the same
+    nsplit — for split factors that give one, two, three and many K steps per work-group, ragged last splits and splits
+    with no step at all (the ring's prologue / steady state / drain paths)."""
+    from insar_unet_ca_amd import engine, _lib
+    from insar_unet_ca_amd._lib import call, ptr
+    dtype = torch.bfloat16
+    ctx = engine.Ctx(dev, dtype)
+    b, _, h, w = shape
+    xfull = _act_from(cf.make_input((b, cin + c_extra, h, w)), dtype, dev)
+    xa = xfull.slice(c_extra, cin) if c_extra else xfull
+    ga = _act_from(cf.make_grad((b, cout, h, w)), dtype, dev)
+    pair = call("insar_wgrad_conv3x_tile", xa.ref, cout)
+    assert pair and call("insar_wgrad_conv3_tile", xa.ref, cout)
+    ksteps = b * h * w // 64
+    xr = xa.nchw().cpu().double()
+    gr = ga.nchw().cpu().double()
+    wv = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, wv, padding=1).backward(gr)
+    slab = 9 * cout * cin
+    for nsplit in sorted({1, 2, 3, max(1, ksteps // 3), max(1, ksteps // 2), ksteps, ksteps + 3, max(1, (ksteps + 4) // 5)}):
+        pa = torch.full((nsplit * slab,), float("nan"), device=dev)
+        pb = torch.full((nsplit * slab,), float("nan"), device=dev)
+        call("insar_wgrad_conv3", xa.ref, ga.ref, ptr(pa), nsplit, _lib.stream_ptr())
+        call("insar_wgrad_conv3x", xa.ref, ga.ref, ptr(pb), nsplit, _lib.stream_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(pa, pb), (nsplit, float((pa - pb).abs().max()))
+        gwt = torch.zeros(cout, cin, 3, 3, device=dev)
+        ctx.wgrad_finish(pb, gwt, nsplit, 9, cout, cin, 0)
+        assert max_rel(gwt, wv.grad) <= KERNEL_TOL * 5, nsplit
+    # and through the engine's own dispatch (cost-model split factor)
+    gwt = torch.zeros(cout, cin, 3, 3, device=dev)
+    engine._wgrad_conv3(ctx, xa, ga, gwt)
+    assert max_rel(gwt, wv.grad) <= KERNEL_TOL * 5
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cin,cout,shape", [
     (64, 128, (2, 64, 40, 56)),      # several 254-pixel tiles, rows shorter than a tile
@@ -642,6 +688,15 @@ def _metrics_from_device(logits, tgt, dev):
     return orc.metrics_from_counts(c[0], c[1], c[2])
 
 
+# (conv / BN / convT tensors, SE fc tensors): gate on the relative deviation of a gradient tensor's NORM from the reference's on
+# G3. The ragged fixture meets the 5 % of the G3r test; the two smooth closed-form ones do not, and not because of this path:
+# torch's own fp32 and fp64 backward disagree by 0.07-0.15 rel-L2 on them (hundreds of pre-activations within rounding of 0,
+# batch statistics over 8-16 values at the bottleneck). Measured here (round 4): b2_64_train worst 0.115 (down4 BN weight),
+# SE fc 0.079; b1_256_train every conv / BN / convT tensor < 0.05, SE fc 0.218 (down4's first Linear: a sum of cancelling
+# terms). Gates = 2 x measured: a layer that is WRONG is off by O(1).
+G3_NORM_TOL = {"b2_64_train": (0.23, 0.16), "b3_48x80_train": (5e-2, 5e-2), "b1_256_train": (5e-2, 0.44)}
+
+
 @pytest.mark.parametrize("tag,shape,training", [
     ("b2_64_train", (2, 2, 64, 64), True),
     ("b3_48x80_train", (3, 2, 48, 80), True),
@@ -679,6 +734,20 @@ def test_unet_golden_fp32(dev, golden, tag, shape, training):
     for k in ("outc.weight", "outc.bias"):
         nrm = float(g3[f"{tag}/grad/{k}/norm"])
         assert abs(float(dict(net.named_parameters())[k].grad.double().norm()) - nrm) <= 1e-3 * nrm, k
+    # ... and the NORM of every gradient tensor against the reference-generated vector (the gate of the G3r test), so that a
+    # wrong layer cannot hide behind the decision-conditioned test's modified oracle: a layer that is wrong is off by O(1),
+    # the ill-conditioning of these fixtures moves norms by per cent. G3_NORM_TOL[tag] holds the gate (measured x 2 where
+    # the 5 % of G3r is not reached; see the table's comment).
+    worst = []
+    for k, p in net.named_parameters():
+        if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
+            continue
+        nrm = float(g3[f"{tag}/grad/{k}/norm"])
+        dev_ = abs(float(p.grad.double().norm()) - nrm) / max(nrm, 1e-30)
+        tol = G3_NORM_TOL[tag][1] if ".fc." in k else G3_NORM_TOL[tag][0]
+        if dev_ > tol:
+            worst.append((round(dev_, 4), k))
+    assert not worst, sorted(worst, reverse=True)[:12]
 
 
 def test_unet_fp32_gradients_golden_generic_position(dev, golden):

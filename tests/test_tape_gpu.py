@@ -17,7 +17,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _run(dev, model_name, dtype, mode, steps, batches, monkeypatch, p_drop=0.0):
+def _run(dev, model_name, dtype, mode, steps, batches, monkeypatch, p_drop=0.0, accum=1, set_to_none=True, reassign_at=None):
     import insar_unet_ca_amd as iu
     from insar_unet_ca_amd import tape
     monkeypatch.setattr(tape, "MODE", mode)
@@ -33,10 +33,18 @@ def _run(dev, model_name, dtype, mode, steps, batches, monkeypatch, p_drop=0.0):
     opt = iu.Adam(net.parameters(), lr=1e-3)
     losses, evals = [], []
     for i in range(steps):
-        x, y = batches[i % len(batches)]
-        opt.zero_grad(set_to_none=True)
-        loss = crit(net(x), y)
-        loss.backward()
+        if reassign_at is not None and i == reassign_at:       # new storage under every parameter and BatchNorm buffer
+            for prm in net.parameters():
+                prm.data = prm.data.clone()
+            for m in net.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.running_mean = m.running_mean.clone()
+                    m.running_var = m.running_var.clone()
+        opt.zero_grad(set_to_none=set_to_none)
+        for k in range(accum):                                  # gradient accumulation: several backwards per optimizer step
+            x, y = batches[(i * accum + k) % len(batches)]
+            loss = crit(net(x), y)
+            loss.backward()
         opt.step()
         losses.append(float(loss.detach()))
         if i % 5 == 4:                                      # a validation pass between training steps
@@ -119,3 +127,59 @@ def test_dropout_advances_under_the_tape(dev, monkeypatch):
     assert off[0] == on[0], (off[0], on[0])
     for k in off[1]:
         assert torch.equal(off[1][k], on[1][k]), k
+
+
+@pytest.mark.parametrize("accum,set_to_none", [(4, True), (3, False), (1, False)])
+def test_tape_with_gradient_accumulation(dev, accum, set_to_none, monkeypatch):
+    """Several training-mode forwards / backwards before the FIRST optimizer step: both recordings are made while no weight is
+    stale, so a tape that baked "no re-layout" into itself would train on stale bf16 copies after the first step (ADVICE r3,
+    high). The re-layout check is a live op of the tape (tape.tape_live): trajectory bit for bit the untaped one."""
+    from insar_unet_ca_amd.data import make_batch
+    batches = [tuple(t.to(dev) for t in make_batch(4 * i, 4, 32)) for i in range(3)]
+    off = _run(dev, "unet", torch.bfloat16, "0", 6, batches, monkeypatch, accum=accum, set_to_none=set_to_none)
+    on = _run(dev, "unet", torch.bfloat16, "1", 6, batches, monkeypatch, accum=accum, set_to_none=set_to_none)
+    _assert_equal(off, on)
+    # the forward tape and a backward tape took over (with live .grad views backward alternates between the two gradient
+    # buffers or stays on one of them: the tape of the other may never leave its recording state)
+    rep = {k: v for r in on[5] for k, v in r.items()}
+    assert all(v.startswith("replaying") for k, v in rep.items() if k[0] == "f") and any(k[0] == "f" for k in rep), rep
+    assert any(v.startswith("replaying") for k, v in rep.items() if k[0] == "b"), rep
+    assert off[0][0] != off[0][-1]                           # and the weights did move
+
+
+@pytest.mark.parametrize("model_name,chan", [("unet", 2), ("deeplab", 1)])
+def test_tape_is_dropped_when_parameter_storage_moves(dev, model_name, chan, monkeypatch):
+    """p.data = ..., a swapped running_mean: the ordinary code re-reads every pointer per call; a tape holds them in prebuilt
+    arguments. The tape's storage fingerprint notices, the tape is recorded again."""
+    from insar_unet_ca_amd.data import make_batch
+    batches = [tuple(t.to(dev) for t in make_batch(4 * i, 4, 64, channels=chan)) for i in range(2)]
+    off = _run(dev, model_name, torch.bfloat16, "0", 12, batches, monkeypatch, reassign_at=6)
+    on = _run(dev, model_name, torch.bfloat16, "1", 12, batches, monkeypatch, reassign_at=6)
+    _assert_equal(off, on)
+    states = [v for rep in on[5] for v in rep.values()]
+    assert states and all(s.startswith("replaying") for s in states), on[5]
+
+
+def test_replay_restores_the_stream_when_a_launch_fails(dev, monkeypatch):
+    """A launch that fails inside a side-stream section of a replay must leave torch's current stream where the caller had it."""
+    import insar_unet_ca_amd as iu
+    from insar_unet_ca_amd import tape, _lib
+    from insar_unet_ca_amd.data import make_batch
+    monkeypatch.setattr(tape, "MODE", "1")
+    x, y = (t.to(dev) for t in make_batch(0, 2, 32))
+    net = iu.UNet(2, 2, True, compute_dtype=torch.bfloat16).to(dev).train()
+    crit = iu.CrossEntropyLoss(ignore_index=255)
+    for _ in range(4):
+        net.zero_grad(set_to_none=True)
+        crit(net(x), y).backward()
+    plan = [pl for lst in net._plans.plans.values() for pl in (lst if isinstance(lst, list) else [lst])][0]
+    st = plan._tapes[plan._tape_key("b")]
+    assert st["state"] == 3
+    ops = list(st["tape"])
+    first_side = next(i for i, op in enumerate(ops) if op[0] == 1)
+    ops[first_side] = (1, lambda *a: -7, ops[first_side][2], "injected failure")
+    before = torch.cuda.current_stream()
+    with pytest.raises(_lib.InsarError):
+        plan._replay(ops, {"dlogits": 0})
+    assert torch.cuda.current_stream() == before
+    torch.cuda.synchronize()

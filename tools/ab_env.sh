@@ -5,8 +5,8 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 N=$1; ARGS=$2; shift 2
 pick='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], d["ms_per_step"], d["value"])'
 for i in $(seq $N); do
-  timeout -k 10 200 python3 $R/bench.py $ARGS --steps 30 --warmup 8 --no-cpu-baseline --no-kernel-timing --no-other-configs 2>/dev/null | python3 -c "$pick" default || exit 1
+  timeout -k 10 200 python3 $R/bench.py --allow-switches $ARGS --steps 30 --warmup 8 --no-cpu-baseline --no-kernel-timing --no-other-configs 2>/dev/null | python3 -c "$pick" default || exit 1
   for E in "$@"; do
-    env ${E//;/ } timeout -k 10 200 python3 $R/bench.py $ARGS --steps 30 --warmup 8 --no-cpu-baseline --no-kernel-timing --no-other-configs 2>/dev/null | python3 -c "$pick" "$E" || exit 1
+    env ${E//;/ } timeout -k 10 200 python3 $R/bench.py --allow-switches $ARGS --steps 30 --warmup 8 --no-cpu-baseline --no-kernel-timing --no-other-configs 2>/dev/null | python3 -c "$pick" "$E" || exit 1
   done
 done

@@ -19,7 +19,7 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
 echo "== rocprof stats (timed region only, two streams)"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/p3" -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/p3.log" 2>&1 || exit 1
 echo "== rocprof stats (single stream)"
-INSAR_SIDE_STREAM=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/p2" -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/p2.log" 2>&1 || exit 1
+INSAR_SIDE_STREAM=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/p2" -- python3 "$R/bench.py" --allow-switches --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/p2.log" 2>&1 || exit 1
 echo "== PMC passes (launch configuration of the timed region: split-K factors for the side stream; the profiler serialises the kernels)"
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pF" -- python3 "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/pF.log" 2>&1 || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pW" -- python3 "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/pW.log" 2>&1 || exit 1
@@ -35,7 +35,7 @@ python3 "$R/tools/pmc_traffic.py" "$OUT/pmc_fetch.csv" "$OUT/pmc_write.csv" "$OU
 python3 "$R/tools/timeline.py" "$OUT/kernel_trace.csv" | tee "$OUT/timeline.txt"
 rm -rf "$OUT/p1" "$OUT/p2" "$OUT/p3" "$OUT/pF" "$OUT/pW" "$OUT/pT" "$OUT/pmc_fetch.csv" "$OUT/pmc_write.csv"      # keep the summaries only
 echo "== SQ counters (one PMC pass, single stream: every kernel alone on the chip)"
-INSAR_SIDE_STREAM=0 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/pS" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/pS.log" 2>&1 && python3 "$R/tools/sq_counters.py" $(ls "$OUT"/pS/*/*_counter_collection.csv | head -n 1) 1e8 | tee "$OUT/pmc_sq_counters.txt"
+INSAR_SIDE_STREAM=0 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/pS" -- python3 "$R/bench.py" --allow-switches --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/pS.log" 2>&1 && python3 "$R/tools/sq_counters.py" $(ls "$OUT"/pS/*/*_counter_collection.csv | head -n 1) 1e8 | tee "$OUT/pmc_sq_counters.txt"
 rm -rf "$OUT/pS"
 echo "== in-kernel stamps (diagnostic build of the library)"
 if [ -f "$R/insar_unet_ca_amd/libinsar_hip_stamps.so" ]; then

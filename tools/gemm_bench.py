@@ -161,6 +161,59 @@ def main():
             for v in vals[1:]:
                 d = (outs[v] - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
                 res.append(f"max|{kname}={v} - {kname}={vals[0]}|/max = {d:.2e}" + (" (bitwise)" if torch.equal(outs[v], ref) else ""))
+        if "x3" in what:       # the 256 x 128 six-phase weight-gradient kernel (wgrad3x.hip) against the 128 x 128 row-of-taps one
+            pairx = call("insar_wgrad_conv3x_tile", x.ref, cout)
+            pair3 = call("insar_wgrad_conv3_tile", x.ref, cout)
+            if pairx and pair3:
+                tmx, tnx = pairx >> 16, pairx & 0xffff
+                tm3, tn3 = pair3 >> 16, pair3 & 0xffff
+                tiles_x = 3 * (cin // tmx) * (cout // tnx)
+                tiles_3 = 3 * (cin // tm3) * (cout // tn3)
+                ks = M // 64
+                cands = []
+                for fill in (1.0, 0.6):
+                    nx = engine._wgrad_nsplit(tiles_x, ks, 9 * cout * cin, tmx, tnx, 2, taps_per_wg=3, fill=fill)
+                    n3 = engine._wgrad_nsplit(tiles_3, ks, 9 * cout * cin, tm3, tn3, 2, taps_per_wg=3, fill=fill)
+                    if fill < 1.0 and engine.WGRAD_GRID_CAP:
+                        nx = min(nx, max(1, engine.WGRAD_GRID_CAP // tiles_x)); n3 = min(n3, max(1, engine.WGRAD_GRID_CAP // tiles_3))
+                    cands.append((fill, n3, nx))
+                extra = sorted({max(1, 128 // tiles_x), max(1, 192 // tiles_x), max(1, 256 // tiles_x), max(1, 512 // tiles_x)})
+                part_ = ctx.wgrad_part(max(max(c[1], c[2]) for c in cands + [(0, 1, e) for e in extra]) * 9 * cout * cin)
+                def fx(n): return lambda: call("insar_wgrad_conv3x", x.ref, g.ref, _lib.ptr(part_), n, _lib.stream_ptr())
+                def f3(n): return lambda: call("insar_wgrad_conv3", x.ref, g.ref, _lib.ptr(part_), n, _lib.stream_ptr())
+                def fin(n): return lambda: ctx.wgrad_finish(part_, grad, n, 9, cout, cin, 0)
+                # bitwise at equal nsplit
+                nchk = cands[0][2]
+                part_.zero_(); f3(nchk)(); torch.cuda.synchronize(); ref = part_[:nchk * 9 * cout * cin].clone()
+                part_.zero_(); fx(nchk)(); torch.cuda.synchronize(); got = part_[:nchk * 9 * cout * cin].clone()
+                res.append(f"bitwise@nsplit={nchk}: {torch.equal(ref, got)} (max diff {(ref - got).abs().max().item():.2e})")
+                for fill, n3, nx in cands:
+                    r3, rx, q3, qx = [], [], [], []
+                    for r in range(4):
+                        r3.append(run(f3(n3))); rx.append(run(fx(nx))); q3.append(run(fin(n3))); qx.append(run(fin(nx)))
+                    res.append(f"\n   fill {fill}: wgrad3 {tm3}x{tn3} nsplit {n3:3d} grid {n3 * tiles_3:4d}: {min(r3):6.1f} us ({flops/min(r3)/1e6:5.0f} TF) + fold {min(q3):5.1f} | "
+                               f"wgrad3x {tmx}x{tnx} nsplit {nx:3d} grid {nx * tiles_x:4d}: {min(rx):6.1f} us ({flops/min(rx)/1e6:5.0f} TF) + fold {min(qx):5.1f}")
+                for n in extra:
+                    t = min(run(fx(n)) for _ in range(3)); q = min(run(fin(n)) for _ in range(2))
+                    res.append(f"\n   wgrad3x nsplit {n:3d} grid {n * tiles_x:4d} steps/wg {ks / n:6.1f}: {t:6.1f} us ({flops/t/1e6:5.0f} TF) + fold {q:5.1f}")
+        if "x3var" in what:    # timing ablations of wgrad3x's K loop (experiment build: make exp EXPNAME=wx EXPFLAGS=-DINSAR_EXP_WX; INSAR_HIP_LIB=...)
+            pairx = call("insar_wgrad_conv3x_tile", x.ref, cout)
+            if pairx and (pairx >> 16) == 256:
+                tiles_x = 3 * (cin // 256) * (cout // 128)
+                n = max(1, 256 // tiles_x)
+                part_ = ctx.wgrad_part(n * 9 * cout * cin)
+                fn = lambda: call("insar_wgrad_conv3x", x.ref, g.ref, _lib.ptr(part_), n, _lib.stream_ptr())
+                names_ = {0: "kernel", 1: "no DMA in loop", 4: "lockstep groups", 8: "no MFMA",
+                          9: "no MFMA, no DMA", 17: "no reads, no DMA (MFMA + barriers)", 25: "barriers only"}
+                rr = {v: [] for v in names_}
+                for r in range(3):
+                    for v in names_:
+                        _lib.tune("wgrad3x_var", v); rr[v].append(run(fn))
+                _lib.tune("wgrad3x_var", 0)
+                steps = (M // 64) / n
+                for v in names_:
+                    t = min(rr[v])
+                    res.append(f"\n   var {v:2d} {names_[v]:36s}: {t:6.1f} us  ({t / steps * 1e3:6.0f} ns per K step, grid {n * tiles_x}, {steps:.1f} steps/wg)")
         if "wgrad" in what:
             us = run(lambda: engine._wgrad_conv3(ctx, x, g, grad)); res.append(f"wgrad(+fold) {us:7.1f} us {flops/us/1e6:7.1f} TF")
         print(f"{name:9s} {cin:4d}->{cout:4d} @{hw:3d}^2 tile_rows {call('insar_igemm_tile_rows', M, cout)}: " + " | ".join(res), flush=True)

@@ -1,0 +1,3 @@
+set -o pipefail
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r4b; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+INSAR_HIP_LIB=$R/insar_unet_ca_amd/libinsar_hip_wx.so timeout -k 10 500 python3 $R/tools/gemm_bench.py --what x3var --only conv2.0,down3.3,down4.3 2>&1 | tee $OUT/x3var.txt

@@ -40,6 +40,16 @@ def main():
     print(f"main queue busy {1e-6 * union(m):.3f} ms ({len(m)} kernels), side queue busy {1e-6 * union(o):.3f} ms ({len(o)} kernels), "
           f"both busy {1e-6 * (union(m) + union(o) - busy):.3f} ms, GPU idle {1e-6 * (t1 - t0 - busy):.3f} ms")
     print(f"sum of kernel durations: forward {1e-6 * sum(r['e'] - r['s'] for r in fw):.3f} ms, rest {1e-6 * sum(r['e'] - r['s'] for r in bw):.3f} ms")
+    # kernels of the step that are not this library's (ATen element-wise kernels, runtime copies / fills): should be none
+    fw_k = collections.Counter()
+    fw_t = 0
+    for r in step:
+        if "at::" in r["n"] or "rocclr" in r["n"] or r["n"].startswith("__amd"):
+            m_ = re.search(r"(\w+Functor)", r["n"])
+            fw_k[m_.group(1) if m_ else r["n"][:40]] += 1
+            fw_t += r["e"] - r["s"]
+    print(f"framework kernels in the step (at::native / __amd_rocclr): {sum(fw_k.values())} launches, {1e-3 * fw_t:.1f} us"
+          + (": " + ", ".join(f"{k} x{v}" for k, v in fw_k.most_common()) if fw_k else ""))
     agg = collections.defaultdict(lambda: [0, 0])
     for r in step:
         agg[(r["n"][:64], "side" if r["Queue_Id"] != mainq else "main")][0] += r["e"] - r["s"]
