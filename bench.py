@@ -179,6 +179,7 @@ def measure(args, world: int, rank: int, dev, dist, iu, engine, make_batch):
     if world > 1:
         dist.barrier()
         model.exposed_events.clear()
+        model.gather_wait_events.clear()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -190,19 +191,33 @@ def measure(args, world: int, rank: int, dev, dist, iu, engine, make_batch):
     elapsed = time.perf_counter() - t0
     dp_info = None
     if world > 1:
+        own = elapsed
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        tmin = torch.tensor([own], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         ev = model.exposed_events
         exposed = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
         t = torch.tensor([exposed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # sharded scheme: time the forward pass's streams sat waiting for parameter buckets (per step: sum over the buckets)
+        gw = model.gather_wait_events
+        gwait = sum(a.elapsed_time(b) for a, b in gw) / max(args.steps, 1)
+        tg = torch.tensor([gwait], dtype=torch.float64, device=dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
         dp_info = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(),
                    "exchange": "reduce_scatter+sharded_adam+all_gather" if args.shard_optimizer else "allreduce",
                    "bucket_mb": args.bucket_mb, "buckets": len(model.sharded.bounds) if model.sharded is not None else None,
                    # max over ranks of the mean time the main stream sat waiting for the gradient exchange after the last
                    # backward kernel (HIP events around DataParallel's wait; 0 = fully overlapped with backward)
-                   "exposed_comm_ms": round(float(t.item()), 3)}
+                   "exposed_comm_ms": round(float(t.item()) + float(tg.item()), 3),
+                   "exposed_gradient_exchange_ms": round(float(t.item()), 3),
+                   # sharded scheme only: the side stream's waits for parameter buckets at the start of forward (they gate a
+                   # stage's first launch through an event: an upper bound of what the main stream actually waited)
+                   "exposed_param_allgather_ms": round(float(tg.item()), 3) if args.shard_optimizer else None,
+                   "rank_ms_per_step_min": round(1e3 * float(tmin.item()) / args.steps, 3),
+                   "rank_ms_per_step_max": round(1e3 * elapsed / args.steps, 3)}
         model.record_exposed = False
 
     # Roofline leg: the same K steps twice more, in the same process, with a HIP-event pair around every GEMM-class

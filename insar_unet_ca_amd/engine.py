@@ -1262,6 +1262,7 @@ def unpack_output(src: Act) -> torch.Tensor:
 
 class UNetPlan(tape.PlanTape):
     """All buffers + the launch sequence of UNet.forward / backward for one input geometry."""
+    per_stage_param_waits = True       # parallel.DataParallel(shard_optimizer=True): see _stage_gates
 
     def __init__(self, net, B: int, H: int, W: int, dtype: torch.dtype, device: torch.device):
         if H < 16 or W < 16:
@@ -1320,6 +1321,7 @@ class UNetPlan(tape.PlanTape):
         self.stage_sizes = self.sink.group_sizes
         self.stage_ends = [sum(self.stage_sizes[:i + 1]) for i in range(len(self.stage_sizes))]
         self._closes = {}
+        self._gate_events = None
         self.busy = False
         self.training = True
         gws = [b.u1.w for b in self.enc + self.dconv if b.u1.w is not None] + [b.u2.w for b in self.enc + self.dconv]
@@ -1337,7 +1339,7 @@ class UNetPlan(tape.PlanTape):
     # ---- forward ----------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, training: bool) -> torch.Tensor:
         """The ordinary launch sequence (_forward_eager) or, in the steady state of a training loop, its launch tape (tape.py)."""
-        if not (self._tape_allowed(training) and self.outc.virtual_grad_ok()):
+        if not (self._tape_allowed(training, not self.net._hooks.get("param_waits")) and self.outc.virtual_grad_ok()):
             return self._forward_eager(x, training)
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
@@ -1357,13 +1359,41 @@ class UNetPlan(tape.PlanTape):
             return logits
         return out
 
+    def _stage_gates(self, waits):
+        """Sharded data parallelism (parallel.DataParallel(shard_optimizer=True), ShardedAdam(defer_gather=True)): the
+        parameter all-gathers of the last optimizer step may still be in flight, issued bucket by bucket in the order this
+        forward pass needs them. On the side stream, in forward order of the backward stages: wait for the stage's bucket
+        (`waits(stage)`), re-lay THAT stage's GEMM weight copies, record an event. Returns gate(stage): the main stream
+        waits for the stage's event right before the first launch that reads the stage's parameters — the first encoder
+        levels run while the decoder's 58 MB are still arriving. (The reference has no distributed code)"""
+        sets = self.weightset.stage_sets(self.sink.groups)
+        n = len(self.sink.groups)
+        if self._gate_events is None:
+            self._gate_events = [torch.cuda.Event() for _ in range(n)]
+        with self.ctx.side_stream():
+            for st in reversed(range(n)):                # forward order: enc0 = last backward stage ... decoder stage 3 + outc = stage 0
+                waits(st)
+                if sets[st] is not None:
+                    sets[st].refresh()
+                self._gate_events[st].record()
+        self.ctx._side_busy = False          # the per-stage events order the main stream; a join would wait for EVERY bucket
+        evs = self._gate_events
+        return lambda st: torch.cuda.current_stream().wait_event(evs[st])
+
     def _forward_eager(self, x: torch.Tensor, training: bool) -> torch.Tensor:
         s = _lib.stream_ptr
         self.training = training
+        waits = self.net._hooks.get("param_waits")
+        gate = None
         # all GEMM-layout weight copies in one launch when the masters moved. The first layer works on the fp32
         # masters, so the re-layout runs on the side stream beside input packing and the first conv / BN / ReLU
         # passes; the first GEMM conv (ConvBN.forward_conv) joins it.
-        if PREP_SIDE:
+        if waits is not None and self.ctx.side is not None:
+            gate = self._stage_gates(waits)
+        elif PREP_SIDE:
+            if waits is not None:
+                for st in range(len(self.sink.groups)):
+                    waits(st)
             with self.ctx.side_stream():
                 self.weightset.refresh()
         else:
@@ -1371,10 +1401,16 @@ class UNetPlan(tape.PlanTape):
         pack_input(x, self.xin)
         sync = self.net._hooks.get("sync_bn") if training else None       # (process group, world) under DataParallel(sync_bn=True)
         for l in range(5):
+            if gate:
+                gate(8 - l)
             self.enc[l].forward(training, sync=sync)          # levels 0-3 write their max-pool too (pool_out)
         for i in range(3):
+            if gate:
+                gate(3 - i)
             self.up[i].forward()
             self.dconv[i].forward(training, sync=sync)
+        if gate:
+            gate(0)
         self.up[3].forward()
         if self.outc.virtual_grad_ok():      # last block: BN/ReLU/gate + outc in one pass, no 64-channel output tensor
             return self.dconv[3].forward(training, self.outc, sync=sync)

@@ -484,6 +484,7 @@ class UNet(nn.Module):
         self.compute_dtype = compute_dtype
         self._plans = _PlanCache()
         self._hooks: dict = {}
+        self.per_stage_param_waits = True      # its plans wait for sharded-DP parameter buckets stage by stage (engine.UNetPlan)
 
     def set_compute_dtype(self, dtype: Optional[torch.dtype]) -> "UNet":
         self.compute_dtype = dtype

@@ -154,7 +154,9 @@ class DataParallel(torch.nn.Module):
         self._bucket = 0
         self.sharded: Optional[ShardedBuckets] = None
         self.flat_p: Optional[torch.Tensor] = None
-        self._gathers: List = []
+        self._gathers: dict = {}               # bucket index -> all-gather in flight (ShardedAdam(defer_gather=True))
+        self._stage_bucket: List[int] = []     # backward stage -> bucket that holds its parameters
+        self.gather_wait_events: List = []     # bench.py: HIP events around each forward-side wait for a parameter bucket
         self.record_exposed = False            # bench.py: HIP events around the wait for the gradient exchange
         self.exposed_events: List = []
         if shard_optimizer:
@@ -164,14 +166,18 @@ class DataParallel(torch.nn.Module):
         module._hooks["on_done"] = self._on_done
         if shard_optimizer:
             module._hooks["grad_mode"] = "none"
-            module._hooks["before_forward"] = self._params_ready
+            module._hooks["before_forward"] = self._before_forward
+            # plans that re-lay their weights stage by stage (engine.UNetPlan) wait for a bucket only when the first layer
+            # that needs it is about to run: the encoder starts while the decoder's buckets are still arriving
+            module._hooks["param_waits"] = self.wait_stage
         if sync_bn:
             # synchronised BatchNorm (U-Net-CA plan): global-batch statistics, i.e. the reference's single-device batch
             # semantics under data parallelism, for two tiny all-reduces per BatchNorm layer and step
             module._hooks["sync_bn"] = (process_group, self.world)
 
     def forward(self, *args, **kwargs):
-        self._params_ready()
+        if not getattr(self.module, "per_stage_param_waits", False):
+            self._params_ready()
         return self.module(*args, **kwargs)
 
     def state_dict(self, *args, **kwargs):
@@ -200,6 +206,8 @@ class DataParallel(torch.nn.Module):
         self.flat_p = flat
         self.flat_params = params
         self.sharded = ShardedBuckets(flat, bucket_bounds(sizes, self.min_elems), self.world, self.rank)
+        closes = plan_buckets(sizes, self.min_elems)
+        self._stage_bucket = [next(b for b, c in enumerate(closes) if st <= c) for st in range(len(sizes))]
 
     def gather_parameters(self, wait: bool = False) -> None:
         """All-gather the updated shards into the flat parameter buffer (after ShardedAdam's kernel), in place: every
@@ -209,9 +217,11 @@ class DataParallel(torch.nn.Module):
         compute streams wait, so the collectives overlap whatever the training loop does between optimizer.step() and the
         next forward (zero_grad, the input copy, logging)."""
         nccl = self.reducer.backend == "nccl"
-        for (b, e), own in reversed(list(zip(self.sharded.bounds, self.sharded.p))):
+        self._params_ready()                          # (a step() without a forward in between: nothing may still be in flight)
+        for k in reversed(range(len(self.sharded.bounds))):
+            (b, e), own = self.sharded.bounds[k], self.sharded.p[k]
             src = own if nccl else own.clone()        # gloo copies the input into the output slot: keep them distinct
-            self._gathers.append(dist.all_gather_into_tensor(self.flat_p[b:e], src, group=self.pg, async_op=True))
+            self._gathers[k] = dist.all_gather_into_tensor(self.flat_p[b:e], src, group=self.pg, async_op=True)
         torch._C._increment_version(self.flat_params)      # cached GEMM-layout copies of the weights are now stale
         if wait:
             self._params_ready()
@@ -221,9 +231,32 @@ class DataParallel(torch.nn.Module):
         self._params_ready()
 
     def _params_ready(self, plan=None) -> None:
-        for w in self._gathers:
-            w.wait()                 # nccl: the current stream waits for the collective; no host sync
+        for k in sorted(self._gathers, reverse=True):      # issue order
+            self._gathers[k].wait()  # nccl: the current stream waits for the collective; no host sync
         self._gathers.clear()
+
+    def _before_forward(self, plan) -> None:
+        """before the first launch of a forward pass: plans without stage-wise weight re-layout wait for every bucket"""
+        if not getattr(plan, "per_stage_param_waits", False):
+            self._params_ready()
+
+    def wait_stage(self, stage: int) -> None:
+        """Make the CURRENT stream wait for the all-gather of the bucket that holds backward stage `stage` (and, issue
+        order being forward-need order, nothing else: buckets the forward pass needs later keep flying)."""
+        if not self._gathers:
+            return
+        k = self._stage_bucket[stage]
+        w = self._gathers.pop(k, None)
+        if w is None:
+            return
+        if self.record_exposed and self.flat_p is not None and self.flat_p.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            w.wait()
+            e1.record()
+            self.gather_wait_events.append((e0, e1))
+        else:
+            w.wait()
 
     @torch.no_grad()
     def sync_buffers(self) -> None:

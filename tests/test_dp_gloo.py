@@ -232,6 +232,19 @@ def _worker_sharded(rank: int, world: int, port: int, out_dir: str):
             gen = torch.Generator().manual_seed(77 * step + rank)
             flat = torch.randn(plan.total, generator=gen) * 1e-2
             plan.sink = _FakeSink(flat)
+            if shard and world == 2 and dp._gathers:
+                # what engine.UNetPlan._stage_gates does at the start of the next forward: wait bucket by bucket, in forward
+                # order of the backward stages; a bucket is only waited for when the first stage that needs it comes up
+                nst = len(plan.stage_sizes)
+                inflight = set(dp._gathers)
+                assert inflight == set(range(len(dp.sharded.bounds)))          # deferred: every bucket still in flight
+                seen = []
+                for st in reversed(range(nst)):
+                    net._hooks["param_waits"](st)
+                    seen.append(set(dp._gathers))
+                    assert dp._stage_bucket[st] not in dp._gathers
+                    assert all(b in dp._gathers for b in inflight if b < dp._stage_bucket[st])   # later-needed buckets keep flying
+                assert not dp._gathers
             _run_backward_hooks(net, plan)
             if shard:
                 opt.step()
