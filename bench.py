@@ -186,17 +186,20 @@ def measure(args, world: int, rank: int, dev, dist, iu, engine, make_batch):
         loss = timed_step(i)
     host_enqueue = time.perf_counter() - t0      # host time to enqueue the K steps (no sync inside a step)
     torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0       # this rank's own K steps, before it meets the others
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     dp_info = None
     if world > 1:
-        own = elapsed
+        own = own_elapsed
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         tmin = torch.tensor([own], dtype=torch.float64, device=dev)
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        tmax = torch.tensor([own], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         ev = model.exposed_events
         exposed = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
         t = torch.tensor([exposed], dtype=torch.float64, device=dev)
@@ -216,8 +219,9 @@ def measure(args, world: int, rank: int, dev, dist, iu, engine, make_batch):
                    # sharded scheme only: the side stream's waits for parameter buckets at the start of forward (they gate a
                    # stage's first launch through an event: an upper bound of what the main stream actually waited)
                    "exposed_param_allgather_ms": round(float(tg.item()), 3) if args.shard_optimizer else None,
+                   # a rank's own K steps up to its device synchronise (before the closing barrier): fastest and slowest rank
                    "rank_ms_per_step_min": round(1e3 * float(tmin.item()) / args.steps, 3),
-                   "rank_ms_per_step_max": round(1e3 * elapsed / args.steps, 3)}
+                   "rank_ms_per_step_max": round(1e3 * float(tmax.item()) / args.steps, 3)}
         model.record_exposed = False
 
     # Roofline leg: the same K steps twice more, in the same process, with a HIP-event pair around every GEMM-class

@@ -222,6 +222,15 @@ int insar_wgrad_conv3(const InsarAct* x, const InsarAct* dy, float* part, int32_
  * insar_wgrad_conv3x_tile: (tile(Cin) << 16) | tile(Cout), or 0 where the layer keeps insar_wgrad_conv3. */
 int insar_wgrad_conv3x_tile(const InsarAct* x, int32_t Cout);
 int insar_wgrad_conv3x(const InsarAct* x, const InsarAct* dy, float* part, int32_t nsplit, void* stream);
+/* The same decomposition for the bf16 layers with 64 or 128 channels on BOTH sides (the 256^2 / 128^2 levels): the tile is
+ * too small to give eight waves a 64 x 64 x three-tap tile each, so the waves of a work-group split the PIXELS of a K step
+ * (KS = 8 / wave tiles slices of 32 pixels) and a work-group writes KS slabs: part[nsplit * KS][9][Cout][Cin], folded by
+ * insar_wgrad_reduce over nsplit * KS slabs (csrc/wgrad3k.hip). A K step (KS * 32 pixels) must lie inside one image row:
+ * insar_wgrad_conv3k_tile returns (tile(Cin) << 16) | tile(Cout) or 0 (insar_wgrad_conv3 then), _slices returns KS.
+ * The sums are partitioned differently from insar_wgrad_conv3's: equal to fp32 summation order, not bit for bit. */
+int insar_wgrad_conv3k_tile(const InsarAct* x, int32_t Cout);
+int insar_wgrad_conv3k_slices(const InsarAct* x, int32_t Cout);
+int insar_wgrad_conv3k(const InsarAct* x, const InsarAct* dy, float* part, int32_t nsplit, void* stream);
 /* grad = sum_split part[...] re-laid out to the torch parameter layout.
  * layout 0: Conv2d (Co,Ci,kh,kw): grad[(co*Ci+ci)*ntaps + tap]
  * layout 1: ConvTranspose2d (Ci,Co,2,2): grad[(ci*Co+co)*ntaps + tap]

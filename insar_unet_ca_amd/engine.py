@@ -362,6 +362,11 @@ WGRAD_FILL_DL = float(os.environ.get("INSAR_WGRAD_FILL_DL", "0.5"))  # ... and f
 WGRAD_FILL_ALONE = float(os.environ.get("INSAR_WGRAD_FILL_ALONE", "1.0"))   # ... and when it has the GPU to itself
 WGRAD_FILL = float(os.environ.get("INSAR_WGRAD_FILL", "0.6"))     # share of the work-group slots a side-stream weight gradient aims at (0.5 until the row tiles made the dgrad chain faster: re-swept, 0.55-0.65 with 0.7 for the transposed convs is 0.09 ms better, profiles/r03_row_tiles.txt)
 WGRAD_ROWS = os.environ.get("INSAR_WGRAD_ROWS", "1") != "0"      # diagnostic: 0 = per-tap weight-gradient kernel everywhere
+WGRAD_K = os.environ.get("INSAR_WGRAD_K", "1") != "0"            # diagnostic: 0 = wgrad3.hip also for the 64 / 128-channel layers (1: wgrad3k.hip, pixel slices per wave)
+# (Cin x Cout) tiles that take wgrad3k.hip. Measured (profiles/r04_wgrad3k.txt): alone 128 x 64 182.7 -> 155.8 us, 128 x 128 77.8 -> 72.4,
+# 64 x 128 50.9 -> 48.3, 64 x 64 102 -> 128 (two ring slots only: slower); in the step every choice is within noise of the
+# 128-tile kernel except 64 x 64 (+0.07 ms): the shallow levels are not bound by the K loop's structure
+WGRAD_K_TILES = set(os.environ.get("INSAR_WGRAD_K_TILES", "128x64,128x128").split(","))
 WGRAD_X = os.environ.get("INSAR_WGRAD_X", "1") != "0"            # diagnostic: 0 = the 128 x 128 row-of-taps kernel (wgrad3.hip) also where the 256 x 128 six-phase kernel (wgrad3x.hip) applies; slabs bit for bit equal at equal nsplit
 FLAT_PP = int(os.environ.get("INSAR_FLAT_PP", "1"))               # flat 3x3 kernel: ping-pong tap steps (0 = plain loop; bitwise equal)
 FLAT_PERSIST = int(os.environ.get("INSAR_FLAT_PERSIST", "2"))     # flat 3x3 kernel: one work-group per CU walking its tiles (bitwise equal): 1 = forward launches, 2 = all (default since round 3: with the BatchNorm-backward sums carried over a work-group's tiles the input-gradient launches gain too, same-box 7.55 -> 7.49 ms/step), 0 = off
@@ -953,6 +958,27 @@ def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
     cin, cout = x.c_len, dy.c_len
     pair = call("insar_wgrad_conv3_tile", x.ref, cout) if WGRAD_ROWS else 0
     pairx = call("insar_wgrad_conv3x_tile", x.ref, cout) if (WGRAD_ROWS and WGRAD_X) else 0
+    pairk = call("insar_wgrad_conv3k_tile", x.ref, cout) if (WGRAD_ROWS and WGRAD_K and not pairx) else 0
+    if pairk and "%dx%d" % (pairk >> 16, pairk & 0xffff) not in WGRAD_K_TILES:
+        pairk = 0
+    if pairk:
+        # 64 / 128 channels a side (csrc/wgrad3k.hip): one round of work-groups over the share of the chip the launch aims at;
+        # a work-group writes KS slabs (its waves split the pixels of a K step)
+        tm, tn = pairk >> 16, pairk & 0xffff
+        ks = call("insar_wgrad_conv3k_slices", x.ref, cout)
+        tiles = 3 * (cin // tm) * (cout // tn)
+        fill = _side_fill(ctx, WGRAD_FILL) if (ctx.side is not None and not (PROFILER is not None and PROFILER.alone)) else WGRAD_FILL_ALONE
+        ksteps = B * H * W // (ks * 32)
+        nsplit = max(1, min(int(256 * fill) // tiles, ksteps))
+        part = ctx.wgrad_part(nsplit * ks * 9 * cout * cin)
+        if PROFILER is not None:
+            nbytes = ctx.esize * B * H * W * (cin + cout) + 4.0 * nsplit * ks * 9 * cout * cin
+            PROFILER.run("wgrad3k_kernel<%d, %d>" % (tm, tn), 2.0 * B * H * W * cin * cout * 9,
+                         lambda: call("insar_wgrad_conv3k", x.ref, dy.ref, ptr(part), nsplit, _lib.stream_ptr()), nbytes)
+        else:
+            call("insar_wgrad_conv3k", x.ref, dy.ref, ptr(part), nsplit, _lib.stream_ptr())
+        ctx.wgrad_finish(part, grad, nsplit * ks, 9, cout, cin, 0)
+        return
     if pair or pairx:
         # three taps of a kernel row per work-group (csrc/wgrad3.hip): a third of the operand staging; where one side has
         # 256 channels and the other 128, the 256 x 128 tile kernel with the six-phase K loop (csrc/wgrad3x.hip)

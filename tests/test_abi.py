@@ -93,6 +93,10 @@ def test_tile_selection_queries_without_a_gpu():
     rowsx = lambda h, w, ci, co, dt: divmod(call("insar_wgrad_conv3x_tile", act(h, w, ci, dt), co), 1 << 16)
     assert rowsx(64, 64, 512, 256, BF16) == (256, 128) and rowsx(16, 16, 1024, 1024, BF16) == (256, 128)
     assert rowsx(64, 64, 128, 256, BF16) == (128, 256) and rowsx(128, 128, 256, 128, BF16) == (256, 128)
+    rowsk = lambda h, w, ci, co, dt: (divmod(call("insar_wgrad_conv3k_tile", act(h, w, ci, dt), co), 1 << 16), call("insar_wgrad_conv3k_slices", act(h, w, ci, dt), co))
+    assert rowsk(256, 256, 64, 64, BF16) == ((64, 64), 8) and rowsk(256, 256, 128, 64, BF16) == ((128, 64), 4)
+    assert rowsk(128, 128, 64, 128, BF16) == ((64, 128), 4) and rowsk(128, 128, 128, 128, BF16) == ((128, 128), 2)
+    assert rowsk(128, 128, 64, 64, BF16) == ((0, 0), 0) and rowsk(256, 256, 64, 64, F32) == ((0, 0), 0)     # a 256-pixel K step needs W % 256 == 0
     assert rowsx(128, 128, 128, 128, BF16) == (0, 0) and rowsx(64, 64, 512, 256, F32) == (0, 0) and rowsx(48, 80, 512, 256, BF16) == (0, 0)
     # statistics slab of the flat 3x3 kernel: one row per M tile; persistent work-groups (flip bit 2) with one N tile carry
     # the sums over their tiles: one row per work-group (= CUs, 256 when no device answers), unless the grid is smaller

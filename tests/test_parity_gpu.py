@@ -240,6 +240,50 @@ def test_wgrad_conv3x_against_float64_and_the_128_tile_kernel(dev, cin, cout, sh
     assert max_rel(gwt, wv.grad) <= KERNEL_TOL * 5
 
 
+@pytest.mark.parametrize("cin,cout,shape,c_extra", [
+    (64, 64, (1, 64, 3, 256), 0),        # 64 x 64: eight pixel slices, a K step = one 256-pixel image row; two ring slots
+    (64, 64, (2, 64, 2, 512), 64),       # two K steps per image row; x is a channel slice of a wider buffer
+    (128, 64, (2, 128, 4, 128), 0),      # 128 x 64: four slices of two wave tiles, three ring slots
+    (64, 128, (1, 64, 5, 256), 0),       # 64 x 128
+    (128, 128, (2, 128, 6, 64), 0),      # 128 x 128: two slices of four wave tiles
+    (128, 128, (1, 128, 1, 64), 0),      # ONE K step in all
+])
+def test_wgrad_conv3k_against_float64(dev, cin, cout, shape, c_extra):
+    """csrc/wgrad3k.hip (64 / 128 channels a side: the waves of a work-group split the pixels of a K step, a work-group writes
+    KS slabs): the folded weight gradient against float64 on the kernel's own operands, for split factors that give one, two,
+    three and many K steps per work-group, ragged last splits and splits without a step; bit for bit reproducible."""
+    from insar_unet_ca_amd import engine, _lib
+    from insar_unet_ca_amd._lib import call, ptr
+    dtype = torch.bfloat16
+    ctx = engine.Ctx(dev, dtype)
+    b, _, h, w = shape
+    xfull = _act_from(cf.make_input((b, cin + c_extra, h, w)), dtype, dev)
+    xa = xfull.slice(c_extra, cin) if c_extra else xfull
+    ga = _act_from(cf.make_grad((b, cout, h, w)), dtype, dev)
+    pair = call("insar_wgrad_conv3k_tile", xa.ref, cout)
+    ks = call("insar_wgrad_conv3k_slices", xa.ref, cout)
+    assert pair == ((128 if cin % 128 == 0 else 64) << 16 | (128 if cout % 128 == 0 else 64)) and ks == 8 // ((pair >> 16) // 64 * ((pair & 0xffff) // 64))
+    ksteps = b * h * w // (ks * 32)
+    xr = xa.nchw().cpu().double()
+    gr = ga.nchw().cpu().double()
+    wv = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, wv, padding=1).backward(gr)
+    slab = 9 * cout * cin
+    for nsplit in sorted({1, 2, 3, max(1, ksteps // 3), max(1, ksteps // 2), ksteps, ksteps + 2}):
+        part = torch.full((nsplit * ks * slab,), float("nan"), device=dev)
+        call("insar_wgrad_conv3k", xa.ref, ga.ref, ptr(part), nsplit, _lib.stream_ptr())
+        again = torch.full((nsplit * ks * slab,), float("nan"), device=dev)
+        call("insar_wgrad_conv3k", xa.ref, ga.ref, ptr(again), nsplit, _lib.stream_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(part, again), nsplit
+        gwt = torch.zeros(cout, cin, 3, 3, device=dev)
+        ctx.wgrad_finish(part, gwt, nsplit * ks, 9, cout, cin, 0)
+        assert max_rel(gwt, wv.grad) <= KERNEL_TOL * 5, nsplit
+    gwt = torch.zeros(cout, cin, 3, 3, device=dev)
+    engine._wgrad_conv3(ctx, xa, ga, gwt)                       # the engine's own dispatch
+    assert max_rel(gwt, wv.grad) <= KERNEL_TOL * 5
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cin,cout,shape", [
     (64, 128, (2, 64, 40, 56)),      # several 254-pixel tiles, rows shorter than a tile

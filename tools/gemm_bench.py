@@ -196,6 +196,36 @@ def main():
                 for n in extra:
                     t = min(run(fx(n)) for _ in range(3)); q = min(run(fin(n)) for _ in range(2))
                     res.append(f"\n   wgrad3x nsplit {n:3d} grid {n * tiles_x:4d} steps/wg {ks / n:6.1f}: {t:6.1f} us ({flops/t/1e6:5.0f} TF) + fold {q:5.1f}")
+        if "k3" in what:       # the pixel-slice weight-gradient kernel (wgrad3k.hip) against the row-of-taps kernel of wgrad3.hip
+            pairk = call("insar_wgrad_conv3k_tile", x.ref, cout)
+            pair3 = call("insar_wgrad_conv3_tile", x.ref, cout)
+            if pairk and pair3:
+                tmk, tnk = pairk >> 16, pairk & 0xffff
+                ksl = call("insar_wgrad_conv3k_slices", x.ref, cout)
+                tm3, tn3 = pair3 >> 16, pair3 & 0xffff
+                tiles_k = 3 * (cin // tmk) * (cout // tnk)
+                tiles_3 = 3 * (cin // tm3) * (cout // tn3)
+                nmax = max(1, 512 // tiles_k)
+                part_ = ctx.wgrad_part(max(nmax * ksl, 1024) * 9 * cout * cin)
+                def fk(n): return lambda: call("insar_wgrad_conv3k", x.ref, g.ref, _lib.ptr(part_), n, _lib.stream_ptr())
+                def f3(n): return lambda: call("insar_wgrad_conv3", x.ref, g.ref, _lib.ptr(part_), n, _lib.stream_ptr())
+                def fin(n): return lambda: ctx.wgrad_finish(part_, grad, n, 9, cout, cin, 0)
+                # against the old kernel's folded gradient
+                n3 = engine._wgrad_nsplit(tiles_3, M // 64, 9 * cout * cin, tm3, tn3, 2, taps_per_wg=3, fill=1.0)
+                f3(n3)(); fin(n3)(); torch.cuda.synchronize(); ref = grad.clone()
+                nk = max(1, 256 // tiles_k)
+                fk(nk)(); fin(nk * ksl)(); torch.cuda.synchronize(); got = grad.clone()
+                res.append(f"max|k - 3|/max|3| = {(got - ref).abs().max().item() / ref.abs().max().item():.2e}")
+                for fill in (1.0, 0.6):
+                    n3 = engine._wgrad_nsplit(tiles_3, M // 64, 9 * cout * cin, tm3, tn3, 2, taps_per_wg=3, fill=fill)
+                    nk = max(1, int(256 * fill) // tiles_k)
+                    r3 = min(run(f3(n3)) for _ in range(3)); q3 = min(run(fin(n3)) for _ in range(2))
+                    rk = min(run(fk(nk)) for _ in range(3)); qk = min(run(fin(nk * ksl)) for _ in range(2))
+                    res.append(f"\n   fill {fill}: wgrad3 {tm3}x{tn3} nsplit {n3:3d} grid {n3 * tiles_3:4d}: {r3:6.1f} us ({flops/r3/1e6:5.0f} TF) + fold {q3:5.1f} | "
+                               f"wgrad3k {tmk}x{tnk} (x{ksl} slices) nsplit {nk:3d} grid {nk * tiles_k:4d}: {rk:6.1f} us ({flops/rk/1e6:5.0f} TF) + fold {qk:5.1f}")
+                for n in sorted({max(1, 128 // tiles_k), max(1, 192 // tiles_k), max(1, 384 // tiles_k), nmax}):
+                    t = min(run(fk(n)) for _ in range(3))
+                    res.append(f"\n   wgrad3k nsplit {n:3d} grid {n * tiles_k:4d}: {t:6.1f} us ({flops/t/1e6:5.0f} TF)")
         if "x3var" in what:    # timing ablations of wgrad3x's K loop (experiment build: make exp EXPNAME=wx EXPFLAGS=-DINSAR_EXP_WX; INSAR_HIP_LIB=...)
             pairx = call("insar_wgrad_conv3x_tile", x.ref, cout)
             if pairx and (pairx >> 16) == 256:
