@@ -20,6 +20,7 @@
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;      // a register quad an inline-asm operand can name
 
 #define C6_THREADS 512
 #define C6_TILE 256
@@ -41,7 +42,7 @@ struct C64Args {
   const char* by; const float* bscale; const float* bshift;   // BatchNorm-backward sums in the stats slab (InsarBstat)
 };
 
-__device__ __forceinline__ void c6_mma(const uint4& wa, const uint4& xb, f32x4_t& acc) {
+__device__ __forceinline__ void c6_mma(const u32x4_t& wa, const uint4& xb, f32x4_t& acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, xb), acc, 0, 0, 0);
 }
 
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(C6_THREADS, 1) void conv3x3_c64_kernel(C64Args a) {
     while (fpix < front) fetch_unit();
   }
 
-  uint4 wr[9][2][NTW];
+  u32x4_t wr[9][2][NTW];
 #pragma unroll
   for (int g9 = 0; g9 < 9; ++g9) {
     const int tap = a.flip ? 8 - g9 : g9;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(C6_THREADS, 1) void conv3x3_c64_kernel(C64Args a) {
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
         const int n = wn * (16 * NTW) + nt * 16 + r16;
-        wr[g9][sub][nt] = *(const uint4*)(a.w + (((long long)tap * a.N + n) * 64 + (kq + 4 * sub) * 8) * 2);
+        wr[g9][sub][nt] = *(const u32x4_t*)(a.w + (((long long)tap * a.N + n) * 64 + (kq + 4 * sub) * 8) * 2);
       }
   }
 
@@ -120,13 +121,13 @@ __global__ __launch_bounds__(C6_THREADS, 1) void conv3x3_c64_kernel(C64Args a) {
   const uint32_t lane_off = (uint32_t)r16 * C6_ROWB;           // + mt*16*128 as an immediate offset
 
   f32x4_t acc[NTW][MT];
-  // stores + BatchNorm partial sums (interior pixels only) of the tile whose sums are in `acc`
-  auto epilogue = [&](int tile) {
+  // (padded row, padded column) of this lane's first pixel of a tile, by reciprocal multiplies (+ one correction step each:
+  // exact for q / img < 2^22 and img < 2^24, which c64_geometry() guarantees), on q + img so that the few negative pixel
+  // indices of the first tile decompose like the others; the other three pixels are 16, 32, 48 further on: one conditional
+  // wrap each instead of the two divisions. okm[mt]: an interior pixel of the buffer; off[mt]: byte offset of this lane's
+  // first channel of it in y (and in the consumer's y of the BS variant: same layout).
+  auto pixel_offsets = [&](int tile, bool (&okm)[MT], long long (&off)[MT]) {
     const int qt = tile * C6_TILE + a.o;
-    // (padded row, padded column) of this lane's first pixel, by reciprocal multiplies (+ one correction step each: exact
-    // for q / img < 2^22 and img < 2^24, which c64_geometry() guarantees), on q + img so that the few negative pixel
-    // indices of the first tile decompose like the others; the other three pixels are 16, 32, 48 further on: one
-    // conditional wrap each instead of the two divisions.
     int hr, wc;
     {
       const int qb = qt + lrow + a.img;
@@ -137,24 +138,67 @@ __global__ __launch_bounds__(C6_THREADS, 1) void conv3x3_c64_kernel(C64Args a) {
       wc = rem - hr * Wp;
       if (wc < 0) { wc += Wp; --hr; } else if (wc >= Wp) { wc -= Wp; ++hr; }
     }
-    if constexpr (BS) {
-      // the consumer's y at this lane's 4 pixels x 2 x 4 channels, all requested before the first use; its scale / shift
-      // re-read per tile (L2 hits) rather than held in 16 registers beside the 144 of the weights
-      bool okm[MT];
-      uint2 yv[MT][NTW];
-      long long off[MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int q = qt + lrow + mt * 16;
-        if (mt > 0) {
-          wc += 16;
-          if (wc >= Wp) { wc -= Wp; ++hr; if (hr >= a.H + 2) hr = 0; }
-        }
-        okm[mt] = q >= 0 && q <= Pm1 && hr >= 1 && hr <= a.H && wc >= 1 && wc <= a.W;
-        off[mt] = ((long long)q * a.Cy + a.cy_off + wn * (16 * NTW) + kq * 4) * 2;
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) yv[mt][nt] = okm[mt] ? *(const uint2*)(a.by + off[mt] + nt * 32) : make_uint2(0u, 0u);
+    for (int mt = 0; mt < MT; ++mt) {
+      const int q = qt + lrow + mt * 16;
+      if (mt > 0) {
+        wc += 16;
+        if (wc >= Wp) { wc -= Wp; ++hr; if (hr >= a.H + 2) hr = 0; }
       }
+      okm[mt] = q >= 0 && q <= Pm1 && hr >= 1 && hr <= a.H && wc >= 1 && wc <= a.W;
+      off[mt] = ((long long)q * a.Cy + a.cy_off + wn * (16 * NTW) + kq * 4) * 2;
+    }
+  };
+  // BS: the consumer's y at this lane's 4 pixels x NTW x 4 channels. The loads are issued right after the first two taps of
+  // a tile and take over those taps' weight registers (the kernel sits at 256): they fly under the other seven taps
+  // (~3 500 cycles) instead of being requested at the head of the epilogue, where their HBM latency was exposed once per
+  // tile (16 tiles x ~2.5 us: the 46 us per launch this variant cost over the plain one); the two taps' weights are
+  // read again (8 KB per wave, L2) at the end of the epilogue.
+  uint2 yv[MT][NTW];
+  auto load_y = [&](int tile) {
+    // unconditional loads (pixels beyond the buffer clamped into it): what they return for halo pixels is never used
+    const int qt = tile * C6_TILE + a.o + lrow;
+    const char* yb = a.by + ((long long)a.cy_off + wn * (16 * NTW) + kq * 4) * 2;
+    const long long ypitch = (long long)a.Cy * 2;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      int q = qt + mt * 16;
+      q = q < 0 ? 0 : (q > Pm1 ? Pm1 : q);
+      const char* yp = yb + q * ypitch;
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) yv[mt][nt] = *(const uint2*)(yp + nt * 32);
+    }
+  };
+  constexpr int NREL = 2;                                      // leading taps whose weights are re-read per tile (BS)
+  auto load_first_weights = [&]() {
+#pragma unroll
+    for (int g9 = 0; g9 < NREL; ++g9) {
+      const int tap = a.flip ? 8 - g9 : g9;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          const int n = wn * (16 * NTW) + nt * 16 + r16;
+          // issued from inline asm: hipcc's own wait for a load it knows about would sit at the first use of these registers,
+          // behind the next tile's LDS-DMA pieces in the queue, and wait for those too (the loop's DMA is invisible to it)
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wr[g9][sub][nt])
+                       : "v"(a.w + (((long long)tap * a.N + n) * 64 + (kq + 4 * sub) * 8) * 2) : "memory");
+        }
+    }
+  };
+  auto wait_first_weights = [&]() {        // ... and waited for by hand: every destination named, so nothing reads them earlier
+    static_assert(NREL == 2 && NTW == 2, "operand list below");
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(wr[0][0][0]), "+v"(wr[0][0][1]), "+v"(wr[0][1][0]), "+v"(wr[0][1][1]),
+                   "+v"(wr[1][0][0]), "+v"(wr[1][0][1]), "+v"(wr[1][1][0]), "+v"(wr[1][1][1]) :: "memory");
+  };
+  // stores + BatchNorm partial sums (interior pixels only) of the tile whose sums are in `acc`
+  auto epilogue = [&](int tile) {
+    bool okm[MT];
+    long long off[MT];
+    pixel_offsets(tile, okm, off);
+    if constexpr (BS) {
+      // the consumer's scale / shift re-read per tile (L2 hits) rather than held in 16 registers beside the weights
       f32x4_t bsc[NTW], bsh[NTW];
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
@@ -185,14 +229,8 @@ __global__ __launch_bounds__(C6_THREADS, 1) void conv3x3_c64_kernel(C64Args a) {
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int q = qt + lrow + mt * 16;
-      if (mt > 0) {
-        wc += 16;
-        if (wc >= Wp) { wc -= Wp; ++hr; if (hr >= a.H + 2) hr = 0; }
-      }
-      const bool ok = q >= 0 && q <= Pm1 && hr >= 1 && hr <= a.H && wc >= 1 && wc <= a.W;
-      if (ok) {
-        char* yp = a.y + ((long long)q * a.Cy + a.cy_off + wn * (16 * NTW) + kq * 4) * 2;
+      if (okm[mt]) {
+        char* yp = a.y + off[mt];
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
           uint2 v;
@@ -261,6 +299,9 @@ __global__ __launch_bounds__(C6_THREADS, 1) void conv3x3_c64_kernel(C64Args a) {
       for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) c6_mma(wr[g9][sub][nt], xf[st & 1][mt], acc[nt][mt]);
+      if constexpr (BS) {
+        if (st == 2 * NREL - 1) load_y(t);                     // the first taps are done: their weight registers carry the y loads now
+      }
     }
 
     // the prefetched rows must have landed before any wave starts the next tile (they had this tile's
@@ -268,7 +309,13 @@ __global__ __launch_bounds__(C6_THREADS, 1) void conv3x3_c64_kernel(C64Args a) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // lgkmcnt: see common.h, dma_drain_and_barrier
 
     epilogue(t);
+    if constexpr (BS) {
+      load_first_weights();                                  // (unconditionally: a guarded re-read would keep the old registers live across the tile)
+    }
     __builtin_amdgcn_s_barrier();
+    if constexpr (BS) {
+      wait_first_weights();            // before the next tile's LDS-DMA pieces are issued
+    }
     rb += C6_TILE;
     if (rb >= R) rb -= R;
   }
