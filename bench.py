@@ -255,12 +255,25 @@ def measure(args, world: int, rank: int, dev, dist, iu, engine, make_batch):
             nparams = 31261122
         else:
             # DeepLabV3-CA: algorithmic FLOPs from the layer shapes of the plan (every tap of every convolution, forward +
-            # input gradient + weight gradient; the 1-channel stem has no input gradient); no ideal-fusion byte model has
-            # been derived for it (SURVEY 8d covers the U-Net), so only the matrix-core position is reported
+            # input gradient + weight gradient; the 1-channel stem has no input gradient) and algorithmic BYTES by the rules
+            # SURVEY 8d states for the U-Net (ideal fusion): a convolution reads its input and writes its output once,
+            # BatchNorm / ReLU / the residual add / the attention scale cost nothing extra (applied on load), backward per
+            # conv + BN unit reads the saved input, writes the input gradient and reads (grad-out, raw-out) once per inherent
+            # reduction pass (two: BatchNorm-backward sums; dgrad / wgrad) => 3 in + 5 out elements per unit; MaxPool(3,2,1)
+            # forward in + out, backward in + g_out + g_in; the channel-attention module one extra read of its input forward
+            # and backward; plus per step 36 bytes per parameter (bf16 shadow + fp32 master + gradient + Adam).
             plan = next(iter(net._plans.plans.values()))[0]
             macs = sum(u.M * u.cin * u.cout * u.k * u.k for u in plan.units) / args.batch
             flop_tile = 3 * 2.0 * macs + 2 * 2.0 * (args.size // 2) ** 2 * 64 * 49
-            name, act_bytes, nparams = "DeepLabV3-CA (ResNet-50 os8 + ASPP + CAM, in=1, classes=2)", None, 39635906
+            elems = 0.0
+            for u in plan.units:
+                m_in = u.x.B * u.x.H * u.x.W
+                elems += 3.0 * m_in * u.cin + 5.0 * u.M * u.cout
+            q = (args.size // 4) ** 2 * 64 * args.batch          # MaxPool(3,2,1) output elements (stem: size/2, 64 channels in)
+            elems += (4 * q + q) + (3 * 4 * q)                    # pool forward in + out, backward in + g_out + g_in (in = 4 q)
+            elems += 2.0 * args.batch * (args.size // 8) ** 2 * 256   # ChannelAttentionModule: one extra read each way
+            name, nparams = "DeepLabV3-CA (ResNet-50 os8 + ASPP + CAM, in=1, classes=2)", 39635906
+            act_bytes = elems * 2 / args.batch
         out = {
             "metric": "InSAR tiles/sec (fwd+bwd) U-Net-CA 256x256" if args.model == "unet" else "InSAR tiles/sec (fwd+bwd) DeepLabV3-CA 256x256 (config 5)",
             "value": round(value, 2), "unit": "tiles/s",
@@ -295,9 +308,10 @@ def measure(args, world: int, rank: int, dev, dist, iu, engine, make_batch):
         out["roofline_step"] = {"bound": bound, "achieved": round(fl if bound == "mfma" else bw, 2),
                                 "peak": peak if bound == "mfma" else PEAK_HBM_GBS, "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
                                 "frac": round(max(fl / peak, bw / PEAK_HBM_GBS), 4),
-                                "algorithmic": (f"{flop_tile / 1e9:.1f} GFLOP and {bytes_tile / 1e6:.0f} MB per tile (SURVEY 8d)" if act_bytes is not None
-                                                else f"{flop_tile / 1e9:.1f} GFLOP per tile (layer shapes of the plan; no byte model)")
-                                               + ", whole step incl. loss and Adam, timed region"}
+                                "algorithmic": (f"{flop_tile / 1e9:.1f} GFLOP and {bytes_tile / 1e6:.0f} MB per tile "
+                                                + ("(SURVEY 8d)" if args.model == "unet" else "(layer shapes of the plan, SURVEY 8d's ideal-fusion rules)")
+                                                + ", whole step incl. loss and Adam, timed region"),
+                                "frac_mfma": round(fl / peak, 4), "frac_hbm": round(bw / PEAK_HBM_GBS, 4)}
         if args.model == "unet" and args.dtype == "bf16" and args.size == 256 and args.batch == 16:
             # whole-step HBM traffic from the PMC passes of this configuration (tools/pmc_traffic.py: every dispatch between
             # two Adam launches), next to the algorithmic bytes of the byte model
@@ -313,8 +327,6 @@ def measure(args, world: int, rank: int, dev, dist, iu, engine, make_batch):
                     out["roofline_step"]["traffic_over_algorithmic"] = round(st["hbm_bytes_per_step"] / alg, 3)
                     out["roofline_step"]["traffic_source"] = os.path.relpath(tpath, ROOT)
                     break
-        if act_bytes is None:
-            out.pop("frac_of_hbm_roofline")
         if timers:
             summ = timers["timed_config"].summary()
             alone = timers["alone"].summary()

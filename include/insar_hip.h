@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define INSAR_ABI_VERSION 4
+#define INSAR_ABI_VERSION 5
 
 enum { INSAR_F32 = 0, INSAR_BF16 = 1 };
 

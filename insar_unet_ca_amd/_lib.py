@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INSAR_HIP_LIB") or os.path.join(_HERE, "libinsar_hip.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 IGEMM_OOB_ZERO = 1
 IGEMM_PINGPONG = 2
 

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(512) void wgrad3x_kernel(Wgrad3xArgs a) {
 #ifdef INSAR_STAMPS
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+  const unsigned long long stamp_t0 = stamp_prev, stamp_r0 = __builtin_amdgcn_s_memrealtime();   // [6] / [7]: shader clock vs 100 MHz
 #endif
   int t;
   {
@@ -357,6 +358,8 @@ __global__ __launch_bounds__(512) void wgrad3x_kernel(Wgrad3xArgs a) {
   }
 #ifdef INSAR_STAMPS
   WX_STAMP(3);          // slab stores
+  stamp_acc[6] = __builtin_amdgcn_s_memtime() - stamp_t0;
+  stamp_acc[7] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
   if (tid == 0) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) atomicAdd(&g_wgrad3x_stamps[(blockIdx.x & 1023) * 8 + k], stamp_acc[k]);

@@ -33,7 +33,7 @@ def report(lib, which, names, fn, flops, grid_hint=""):
     getter(buf.ctypes.data, 0)
     s = buf.reshape(1024, 8).astype(np.float64).sum(0) / reps
     clock = ""
-    if which == "igemm" and s[7] > 0:          # [6] shader-clock ticks, [7] 100 MHz ticks of the same interval, summed over work-groups
+    if which in ("igemm", "wgrad3x") and s[7] > 0:          # [6] shader-clock ticks, [7] 100 MHz ticks of the same interval, summed over work-groups
         ghz = s[6] / s[7] * 0.1
         clock = f"clock {ghz:.2f} GHz -> dense bf16 peak {2500.0 * ghz / 2.4:.0f} TF, kernel at {100 * flops / us / 1e6 / (2500.0 * ghz / 2.4):.0f}% of it | "
         s = s.copy(); s[6] = s[7] = 0
@@ -77,6 +77,17 @@ def main():
                 part = ctx.wgrad_part(nsp * 9 * cout * cin)
                 print(f"   wgrad3 fill {fill}", report(lib, "wgrad3", W3, lambda: call("insar_wgrad_conv3", x.ref, g.ref, ptr(part), nsp, _lib.stream_ptr()), flops,
                                                       f"tile {tm}x{tn} grid {tiles * nsp} "), flush=True)
+        pairx = call("insar_wgrad_conv3x_tile", x.ref, cout)
+        if pairx:          # the 256 x 128 six-phase kernel (csrc/wgrad3x.hip)
+            tm, tn = pairx >> 16, pairx & 0xffff
+            tiles = 3 * (cin // tm) * (cout // tn)
+            for fill in (1.0, 0.6):
+                nsp = engine._wgrad_nsplit(tiles, M // 64, 9 * cout * cin, tm, tn, 2, taps_per_wg=3, fill=fill)
+                if fill < 1.0:
+                    nsp = min(nsp, max(1, engine.WGRAD_GRID_CAP // tiles))
+                part = ctx.wgrad_part(nsp * 9 * cout * cin)
+                print(f"   wgrad3x fill {fill}", report(lib, "wgrad3x", W3, lambda: call("insar_wgrad_conv3x", x.ref, g.ref, ptr(part), nsp, _lib.stream_ptr()), flops,
+                                                       f"tile {tm}x{tn} grid {tiles * nsp} "), flush=True)
 
 
 if __name__ == "__main__":
