@@ -362,7 +362,7 @@ WGRAD_FILL_DL = float(os.environ.get("INSAR_WGRAD_FILL_DL", "0.5"))  # ... and f
 WGRAD_FILL_ALONE = float(os.environ.get("INSAR_WGRAD_FILL_ALONE", "1.0"))   # ... and when it has the GPU to itself
 WGRAD_FILL = float(os.environ.get("INSAR_WGRAD_FILL", "0.6"))     # share of the work-group slots a side-stream weight gradient aims at (0.5 until the row tiles made the dgrad chain faster: re-swept, 0.55-0.65 with 0.7 for the transposed convs is 0.09 ms better, profiles/r03_row_tiles.txt)
 WGRAD_ROWS = os.environ.get("INSAR_WGRAD_ROWS", "1") != "0"      # diagnostic: 0 = per-tap weight-gradient kernel everywhere
-WGRAD_K = os.environ.get("INSAR_WGRAD_K", "1") != "0"            # diagnostic: 0 = wgrad3.hip also for the 64 / 128-channel layers (1: wgrad3k.hip, pixel slices per wave)
+WGRAD_K = os.environ.get("INSAR_WGRAD_K", "0") != "0"            # 1 = wgrad3k.hip (pixel slices per wave) for the 64 / 128-channel layers named by INSAR_WGRAD_K_TILES. Off: faster alone on two tile shapes, but in the step 6.90 vs 6.915 ms in three interleaved rounds (its KS slabs per work-group cost more fold traffic than the loop saves)
 # (Cin x Cout) tiles that take wgrad3k.hip. Measured (profiles/r04_wgrad3k.txt): alone 128 x 64 182.7 -> 155.8 us, 128 x 128 77.8 -> 72.4,
 # 64 x 128 50.9 -> 48.3, 64 x 64 102 -> 128 (two ring slots only: slower); in the step every choice is within noise of the
 # 128-tile kernel except 64 x 64 (+0.07 ms): the shallow levels are not bound by the K loop's structure

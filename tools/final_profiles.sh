@@ -5,8 +5,10 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/${1:-final}
+PART=${2:-all}          # a | b | all: the pass in two gpurun calls (each under the 20-minute limit of a call)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+if [ "$PART" != "b" ]; then
 echo "== pytest"; timeout -k 10 900 python3 -m pytest "$R/tests" -m gpu -q -p no:cacheprovider > "$OUT/pytest_gpu.log" 2>&1; tail -n 2 "$OUT/pytest_gpu.log"
 echo "== race screens"
 RUNS=40 STEPS=24 timeout -k 10 200 python3 "$R/tools/debug_race_steps.py" 2>/dev/null | tee "$OUT/race_steps.log" || exit 1
@@ -34,6 +36,8 @@ cp $(ls "$OUT"/pT/*/*_kernel_trace.csv | head -n 1) "$OUT/kernel_trace.csv"
 python3 "$R/tools/pmc_traffic.py" "$OUT/pmc_fetch.csv" "$OUT/pmc_write.csv" "$OUT/pmc_traffic.json" "timed region (weight gradients split for 0.6 of the work-group slots, as beside the dgrad chain)" | tee "$OUT/pmc_traffic.txt"
 python3 "$R/tools/timeline.py" "$OUT/kernel_trace.csv" | tee "$OUT/timeline.txt"
 rm -rf "$OUT/p1" "$OUT/p2" "$OUT/p3" "$OUT/pF" "$OUT/pW" "$OUT/pT" "$OUT/pmc_fetch.csv" "$OUT/pmc_write.csv"      # keep the summaries only
+fi
+if [ "$PART" = "a" ]; then echo "part a done"; exit 0; fi
 echo "== SQ counters (one PMC pass, single stream: every kernel alone on the chip)"
 INSAR_SIDE_STREAM=0 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/pS" -- python3 "$R/bench.py" --allow-switches --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/pS.log" 2>&1 && python3 "$R/tools/sq_counters.py" $(ls "$OUT"/pS/*/*_counter_collection.csv | head -n 1) 1e8 | tee "$OUT/pmc_sq_counters.txt"
 rm -rf "$OUT/pS"
@@ -53,6 +57,8 @@ timeout -k 10 300 python3 "$R/bench.py" --graph on --no-cpu-baseline --no-kernel
 timeout -k 10 300 python3 "$R/bench.py" --graph off --no-cpu-baseline --no-kernel-timing --no-other-configs --steps 30 --warmup 5 > "$OUT/bench_eager.json" 2> "$OUT/bench_eager.err"; cut -c1-200 "$OUT/bench_eager.json"
 echo "== microbench: ping-pong K loop, same-process A/B"
 timeout -k 10 300 python3 "$R/tools/gemm_bench.py" --only down2.3,conv2.0,conv1.0 --what pp 2>/dev/null | tee "$OUT/gemm_pingpong_ab.txt"
+echo "== microbench: 256 x 128 six-phase weight gradient (wgrad3x.hip) against the 128-tile kernel, every layer it serves"
+timeout -k 10 300 python3 "$R/tools/gemm_bench.py" --what x3 --only down2.3,conv2.0,down3.0,down3.3,conv1.0,down4.0,down4.3,conv3.0,down2.0 2>/dev/null | tee "$OUT/wgrad3x_microbench.txt"
 echo "== 2-rank rehearsal (gloo, both ranks on the one GPU: exercises the bucketed reducer inside backward)"
 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 "$R/bench.py" --gpus 2 --steps 3 --warmup 1 --backend gloo --no-cpu-baseline --no-kernel-timing > "$OUT/bench_dp2_gloo.json" 2> "$OUT/bench_dp2_gloo.err"; cut -c1-160 "$OUT/bench_dp2_gloo.json"
 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 "$R/bench.py" --gpus 2 --steps 3 --warmup 1 --backend gloo --shard-optimizer --no-cpu-baseline --no-kernel-timing > "$OUT/bench_dp2_gloo_sharded.json" 2> "$OUT/bench_dp2_gloo_sharded.err"; cut -c1-160 "$OUT/bench_dp2_gloo_sharded.json"
