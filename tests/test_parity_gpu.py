@@ -240,6 +240,45 @@ def test_wgrad_conv3x_against_float64_and_the_128_tile_kernel(dev, cin, cout, sh
     assert max_rel(gwt, wv.grad) <= KERNEL_TOL * 5
 
 
+@pytest.mark.parametrize("cin,cout,shape,nsplit", [
+    (512, 256, (16, 512, 64, 64), 12),   # conv2.0 of config 2 in the step's launch configuration (85 K steps per work-group)
+    (1024, 1024, (16, 1024, 16, 16), 2), # down4.3: four image rows per K step, 32 steps per work-group
+    (256, 128, (4, 256, 32, 64), 9),     # ragged split: 128 K steps over 9 splits
+])
+def test_wgrad_conv3x_race_screen(dev, cin, cout, shape, nsplit):
+    """The six-phase K loop is a NEW synchronisation structure (three-slot ring, one counted vmcnt per step, two wave groups a
+    barrier apart): a read that runs ahead of the wait that retires its slot passes every reference check whenever the DMA
+    happens to land first. Screen: the same launch 150 times, half of them beside a stream that keeps the memory system busy
+    (the situation in which round 1's WAR race showed), every slab bit for bit the first one."""
+    from insar_unet_ca_amd import engine, _lib
+    from insar_unet_ca_amd._lib import call, ptr
+    dtype = torch.bfloat16
+    b, _, h, w = shape
+    xa = engine.Act.alloc(b, h, w, cin, dtype, dev)
+    ga = engine.Act.alloc(b, h, w, cout, dtype, dev)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    xa.buf[:, 1:-1, 1:-1] = torch.randn((b, h, w, cin), device=dev, generator=gen).to(dtype)
+    ga.buf[:, 1:-1, 1:-1] = torch.randn((b, h, w, cout), device=dev, generator=gen).to(dtype)
+    assert call("insar_wgrad_conv3x_tile", xa.ref, cout)
+    n = nsplit * 9 * cout * cin
+    ref = torch.empty(n, device=dev)
+    call("insar_wgrad_conv3x", xa.ref, ga.ref, ptr(ref), nsplit, _lib.stream_ptr())
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    noise = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    out = torch.empty(n, device=dev)
+    bad = 0
+    for it in range(150):
+        if it % 2:
+            with torch.cuda.stream(side):
+                noise.copy_(noise.flip(0))                        # 128 MB of traffic beside the launch
+        out.fill_(float("nan"))
+        call("insar_wgrad_conv3x", xa.ref, ga.ref, ptr(out), nsplit, _lib.stream_ptr())
+        torch.cuda.synchronize()
+        bad += int(not torch.equal(out, ref))
+    assert bad == 0, f"{bad} of 150 launches differ from the first"
+
+
 @pytest.mark.parametrize("cin,cout,shape,c_extra", [
     (64, 64, (1, 64, 3, 256), 0),        # 64 x 64: eight pixel slices, a K step = one 256-pixel image row; two ring slots
     (64, 64, (2, 64, 2, 512), 64),       # two K steps per image row; x is a channel slice of a wider buffer
