@@ -27,21 +27,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 #define FL_THREADS 512
 #define FL_ROWB 128
 
-struct FlatArgs {
-  const char* x; const char* w; char* y; float* stats;
-  long long P;                 // B*(H+2)*(W+2) padded pixels
-  int B, H, W;
-  int Cx, cx_off, K;
-  int Cy, cy_off, N;
-  int kc_count, flip;
-  int persist;
-  int carry;                   // persistent + one N tile: BatchNorm sums carried over the tiles, slab row = blockIdx.x
-  int num_mtiles, num_ntiles;
-  int total_tiles;             // num_mtiles * num_ntiles
-  int lw;                      // row tiles: log2(W)
-  int dil;                     // dilated row tiles (GEO = 2): dilation of the 3x3 taps; taps beyond the one-pixel halo read zeros
-  const char* by; const float* bscale; const float* bshift;   // BatchNorm-backward sums in the stats slab (InsarBstat)
-};
+#include "flat_args.h"
 
 template <typename T> struct FMma;
 template <> struct FMma<bf16_t> {
@@ -614,7 +600,7 @@ extern "C" int insar_conv3x3_flat_stat_rows(const InsarAct* x, int32_t N, int32_
   const int mt = (flip & 8) ? (int)(((long long)x->B * x->H * x->W) / FL_BM) : flat_mtiles(flat_pixels(*x));
   if (!(flip & 4) || (flip & 8)) return mt;
   const int bn = ((N % 128) == 0 && !(flip & 16)) ? 128 : 64;
-  const int cus = insar_num_cus() & ~7;
+  const int cus = (flip & 32) ? insar_flat2_persistent_grid() : (insar_num_cus() & ~7);      // bit 5: two work-groups per CU
   const long long grid = (long long)mt * (N / bn);
   return (cus >= 8 && grid > cus && N / bn == 1) ? cus : mt;
 }
@@ -652,7 +638,7 @@ static int flat_impl(const InsarAct* x, const InsarAct* y, const void* w, int32_
   if (x->dtype != y->dtype) INSAR_FAIL(INSAR_E_DTYPE, "insar_conv3x3_flat: dtype differ");
   if (x->B != y->B || x->H != y->H || x->W != y->W) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: x/y grids differ");
   const int es = x->dtype == INSAR_BF16 ? 2 : 4;
-  const int bke = FL_ROWB / es;
+  const int bke = (flip & 32) ? 32 : FL_ROWB / es;      // bit 5 (conv3x3_flat2.hip): 32-channel slabs
   if (x->c_len % bke) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: K=%d must be a multiple of %d", x->c_len, bke);
   if (y->c_len % 64) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: N=%d must be a multiple of 64", y->c_len);
   if (!insar_aligned16(w)) INSAR_FAIL(INSAR_E_ALIGN, "insar_conv3x3_flat: weights not 16-byte aligned");
@@ -680,7 +666,7 @@ static int flat_impl(const InsarAct* x, const InsarAct* y, const void* w, int32_
     if (!flat_rows_geometry(*x, a.dil)) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: row tiles need bf16, W a power of two in 16..256, H a multiple of 256 / W and 256 / W * (W + 2 * dilation) <= 320 (got %d x %d, dilation %d)", x->H, x->W, a.dil);
     // the channel conditions insar_conv3x3_flat_rows_ok / _dil_ok promise, re-checked for a direct caller of the C ABI
     if (x->c_len % 64 || y->c_len % 64) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: row tiles need K and N multiples of 64 (got %d, %d)", x->c_len, y->c_len);
-    if (flip & 4) INSAR_FAIL(INSAR_E_ARG, "insar_conv3x3_flat: row tiles (flip bit 3) have no persistent form (flip bit 2)");
+    if (flip & (4 | 32)) INSAR_FAIL(INSAR_E_ARG, "insar_conv3x3_flat: row tiles (flip bit 3) have no persistent (bit 2) or two-work-group (bit 5) form");
     a.num_mtiles = (int)(((long long)x->B * x->H * x->W) / FL_BM);
     a.lw = 0;
     while ((1 << a.lw) < x->W) ++a.lw;
@@ -690,6 +676,10 @@ static int flat_impl(const InsarAct* x, const InsarAct* y, const void* w, int32_
     }
     if (a.by) return wide ? launch_flat<bf16_t, 128, true, true, 1>(a, s) : launch_flat<bf16_t, 64, true, true, 1>(a, s);
     return wide ? launch_flat<bf16_t, 128, true, false, 1>(a, s) : launch_flat<bf16_t, 64, true, false, 1>(a, s);
+  }
+  if (flip & 32) {      // two co-resident 4-wave work-groups per CU (conv3x3_flat2.hip): bf16, flat geometry
+    if (x->dtype != INSAR_BF16) INSAR_FAIL(INSAR_E_DTYPE, "insar_conv3x3_flat: the two-work-group kernel (flip bit 5) is bf16 only");
+    return insar_flat2_launch(a, wide ? 128 : 64, a.by != nullptr, s);
   }
   if (a.by) {           // bf16: the ping-pong loop whatever the flag says (same results bit for bit)
     if (x->dtype == INSAR_BF16) return wide ? launch_flat<bf16_t, 128, true, true>(a, s) : launch_flat<bf16_t, 64, true, true>(a, s);

@@ -379,6 +379,10 @@ STAT_PREFOLD_ROWS = int(os.environ.get("INSAR_STAT_PREFOLD_ROWS", "1024"))
 # 64^2 / 128^2 levels) go to the flat kernel's row-tile geometry instead (the dx taps share one staged A tile, same tile count:
 # 12-24 % faster per launch, tools/gemm_bench.py --what rows -> profiles/r03_row_tiles.txt). 0 = per-tap kernel everywhere.
 FLAT_ROWS = os.environ.get("INSAR_FLAT_ROWS", "1") != "0"
+# flat 3x3 kernel of the 256^2 / 128^2 levels as two co-resident 4-wave work-groups per CU (csrc/conv3x3_flat2.hip: one group's
+# prologue / epilogue under the other's K loop, 128 x 64 wave tiles): 1 = with FLAT_PERSIST's persistent grids (2 per CU),
+# 2 = one work-group per tile, 0 = the 8-wave kernel (results differ by fp32 summation order only)
+FLAT2 = int(os.environ.get("INSAR_FLAT2", "0"))
 BSTAT_FUSE = os.environ.get("INSAR_BSTAT_FUSE", "1") != "0"      # diagnostic: 0 = BatchNorm-backward sums always in a pass of their own
 BSTAT_C64 = os.environ.get("INSAR_BSTAT_C64", "1") != "0"       # the 64 -> 64 kernel's variant of it. Alone it costs more than it saves (8-byte y loads from the accumulator layout: 89 -> 140 us per launch against the 43 us reduce pass it replaces), in the step it wins (same-box A/B 7.70 -> 7.61 ms: one launch less on the dgrad chain beside the weight-gradient stream)
 WGRAD_LATE = os.environ.get("INSAR_WGRAD_ORDER", "before") == "after"      # diagnostic / tuning switch, see ConvBN.backward
@@ -436,6 +440,12 @@ def _flat_persist(flip: int) -> bool:
     return FLAT_PERSIST == 2 or (FLAT_PERSIST == 1 and not (flip & 1))
 
 
+def _flat_flags(flip: int, x: Act) -> int:
+    """flip bits of a flat-geometry launch: bit 2 persistent work-groups, bit 5 the two-work-group kernel (bf16)."""
+    two = FLAT2 and x.code == _lib.BF16
+    return (32 if two else 0) | (4 if (_flat_persist(flip) and not (two and FLAT2 == 2)) else 0)
+
+
 def _rows_flags(x: Act, N: int) -> int:
     """flip bits (8 | 16) of the flat kernel's row-tile geometry for a 3x3 conv of x's grid to N channels, or 0 where the
     per-tap kernel keeps the layer: fp32, grids the geometry does not cover, and wherever the per-tap kernel runs its
@@ -450,7 +460,7 @@ def _rows_flags(x: Act, N: int) -> int:
 
 
 def _conv3x3_flat(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[torch.Tensor], bstat=None, geo: int = 0) -> None:
-    flags = flip | (2 if (FLAT_PP or geo) else 0) | (4 if (_flat_persist(flip) and not geo) else 0) | geo
+    flags = flip | (2 if (FLAT_PP or geo) else 0) | (0 if geo else _flat_flags(flip, x)) | geo
     if bstat is not None:
         bs = _lib.InsarBstat(bstat[0].buf.data_ptr(), ptr(bstat[1]), ptr(bstat[2]))
         fn = lambda: call("insar_conv3x3_flat_bstat", x.ref, y.ref, ptr(w), flags, ptr(stats), C.byref(bs), _lib.stream_ptr())
@@ -461,6 +471,8 @@ def _conv3x3_flat(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[to
         tag = "conv3x3_flat_kernel<%s, %d>%s%s" % ("float" if x.code == _lib.F32 else "bf16_t",
                                                    128 if (y.c_len % 128 == 0 and not (geo & 16)) else 64,
                                                    (" row tiles" + (" dilated" if geo >> 8 else "")) if geo else "", " +bstat" if bstat is not None else "")
+        if flags & 32:
+            tag = "conv3x3_flat2_kernel<%d, %s>" % (128 if y.c_len % 128 == 0 else 64, "true" if bstat is not None else "false")
         PROFILER.run(tag, flops, fn)
         return
     fn()
@@ -644,7 +656,7 @@ class ConvBN:
         elif self.c64:
             self.stat_rows = call("insar_igemm_num_mtiles", self.M, self.cout)
         elif self.flat_fwd:
-            self.stat_rows = call("insar_conv3x3_flat_stat_rows", x.ref, self.cout, 4 if _flat_persist(0) else 0)
+            self.stat_rows = call("insar_conv3x3_flat_stat_rows", x.ref, self.cout, _flat_flags(0, x))
         else:
             self.stat_rows = call("insar_igemm_num_mtiles", self.M, self.cout)
         self.stats = ctx.f32(self.stat_rows, 2, self.cout)
@@ -912,7 +924,7 @@ class ConvBN:
             elif self.flat_bwd and not self.c64:
                 slab = None
                 if bstat_for is not None and BSTAT_FUSE and not bstat_se and _same_layout(dx, bstat_for.y):
-                    slab = bstat_for.bstat_slab(call("insar_conv3x3_flat_stat_rows", self.dy.ref, self.cin, 4 if _flat_persist(1) else 0), False)
+                    slab = bstat_for.bstat_slab(call("insar_conv3x3_flat_stat_rows", self.dy.ref, self.cin, _flat_flags(1, self.dy)), False)
                 if slab:
                     _conv3x3_flat(self.dy, dx, self.w.dgrad(), 1, slab[0], bstat=slab[1])
                     bstat_for.bred_ready = True

@@ -101,11 +101,16 @@ def test_conv_transpose_input_gradient_sums(dev, dtype):
     assert (slab.double().sum(0) - ref_tot).abs().max().item() <= 2e-5 * ref_tot.abs().max().item()
 
 
+@pytest.mark.parametrize("two", [0, 1, 2])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cin,cout,B,hw", [(128, 128, 16, 64), (64, 128, 4, 128)])
-def test_flat_kernel_epilogue_sums_against_the_reduce_pass(dev, dtype, cin, cout, B, hw):
+def test_flat_kernel_epilogue_sums_against_the_reduce_pass(dev, dtype, cin, cout, B, hw, two, monkeypatch):
+    """two: the two-work-group build of the kernel (csrc/conv3x3_flat2.hip; bf16), persistent (1) and one tile per group (2)."""
     from insar_unet_ca_amd import engine
     from insar_unet_ca_amd._lib import call
+    if two and dtype != torch.bfloat16:
+        pytest.skip("the two-work-group kernel is bf16 only")
+    monkeypatch.setattr(engine, "FLAT2", two)
     ctx = engine.Ctx(dev, dtype)
     dy = _rand_act(B, hw, hw, cout, dtype, dev, 5)
     y = _rand_act(B, hw, hw, cin, dtype, dev, 6)
@@ -115,7 +120,7 @@ def test_flat_kernel_epilogue_sums_against_the_reduce_pass(dev, dtype, cin, cout
     p = torch.nn.Parameter(torch.randn(cout, cin, 3, 3, device=dev) * 0.05)
     wd = engine.GemmWeight(ctx, p, "conv3").dgrad()
     scale, shift = torch.randn(cin, device=dev), torch.randn(cin, device=dev) * 0.3
-    rows = call("insar_conv3x3_flat_stat_rows", dy.ref, cin, 4 if engine._flat_persist(1) else 0)
+    rows = call("insar_conv3x3_flat_stat_rows", dy.ref, cin, engine._flat_flags(1, dy))
     slab = torch.zeros(rows, 2, cin, device=dev)
     engine._conv3x3_flat(dy, dx, wd, 1, slab, bstat=(y, scale, shift))
     torch.cuda.synchronize()

@@ -359,6 +359,60 @@ def test_conv3x3_flat_against_float64(dev, dtype, cin, cout, shape):
     assert _halo_abs(dxa) == 0.0
 
 
+@pytest.mark.parametrize("cin,cout,shape", [
+    (64, 128, (2, 64, 40, 56)),      # several 254-pixel tiles, rows shorter than a tile; two 32-channel slabs
+    (128, 64, (1, 128, 33, 300)),    # rows longer than a tile, 64-column tiles (64 x 64 wave tiles)
+    (32, 64, (3, 32, 30, 30)),       # one slab: the loop is its tail only; tiles straddle image boundaries
+    (128, 128, (4, 128, 128, 128)),  # the 128^2 level's shape: more tiles than persistent work-groups (carried sums)
+    (256, 128, (1, 256, 32, 32)),    # eight slabs per tap
+])
+def test_conv3x3_flat_two_work_group_kernel_against_float64(dev, cin, cout, shape):
+    """csrc/conv3x3_flat2.hip (flip bit 5: two co-resident 4-wave work-groups per CU, 32-channel slabs, 128 x 64 wave tiles),
+    one tile per work-group and persistent (bit 2): forward with BatchNorm partial sums and input gradient against float64,
+    zero halos, against the 8-wave kernel to bf16 rounding of its fp32 sums (the summation order differs), and bit for bit
+    run to run over 10 launches each (the second work-group of a CU runs beside the first: a race screen too)."""
+    from insar_unet_ca_amd import _lib, engine
+    from insar_unet_ca_amd._lib import call, ptr
+    dtype = torch.bfloat16
+    ctx = engine.Ctx(dev, dtype)
+    b, _, h, w = shape
+    xa = _act_from(cf.make_input_random(shape, seed=5), dtype, dev)
+    ga = _act_from(cf.make_input_random((b, cout, h, w), seed=6), dtype, dev)
+    p = torch.nn.Parameter(cf.fill_tensor("weight", (cout, cin, 3, 3), 11).to(dev))
+    gw = engine.GemmWeight(ctx, p, "conv3")
+    wr = gw.fwd().float().cpu().reshape(3, 3, cout, cin).permute(2, 3, 0, 1).double()
+    want_y = F.conv2d(xa.nchw().cpu().double(), wr, padding=1)
+    want_dx = F.conv_transpose2d(ga.nchw().cpu().double(), wr, padding=1)
+    rows = call("insar_conv3x3_flat_num_mtiles", xa.ref)
+    y8 = engine.Act.alloc(b, h, w, cout, dtype, dev)
+    if cin % 64 == 0:
+        call("insar_conv3x3_flat", xa.ref, y8.ref, ptr(gw.fwd()), 2, 0, _lib.stream_ptr())
+    for flags in (32, 32 | 4):
+        first = None
+        for rep in range(10):
+            ya = engine.Act.alloc(b, h, w, cout, dtype, dev)
+            dxa = engine.Act.alloc(b, h, w, cin, dtype, dev)
+            prow = call("insar_conv3x3_flat_stat_rows", xa.ref, cout, flags)
+            assert prow <= rows
+            stats = torch.zeros(rows, 2, cout, device=dev)
+            call("insar_conv3x3_flat", xa.ref, ya.ref, ptr(gw.fwd()), flags, ptr(stats), _lib.stream_ptr())
+            if cin % 64 == 0:          # (the input gradient has cin output columns: multiples of 64)
+                call("insar_conv3x3_flat", ga.ref, dxa.ref, ptr(gw.dgrad()), flags | 1, 0, _lib.stream_ptr())
+            if first is None:
+                first = (ya.buf.clone(), dxa.buf.clone(), stats.clone())
+                assert max_rel(ya.nchw(), want_y) <= 6e-3, flags
+                assert cin % 64 or max_rel(dxa.nchw(), want_dx) <= 6e-3, flags
+                assert _halo_abs(ya) == 0.0 and _halo_abs(dxa) == 0.0
+                got = ya.nchw().double().cpu()
+                assert float(stats[prow:].abs().max() if prow < rows else 0.0) == 0.0
+                assert max_rel(stats.sum(0)[0], got.sum((0, 2, 3))) <= 1e-4
+                assert max_rel(stats.sum(0)[1], (got ** 2).sum((0, 2, 3))) <= 1e-4
+                if cin % 64 == 0:
+                    assert max_rel(ya.nchw(), y8.nchw().double().cpu()) <= 8e-3      # one bf16 ulp of the largest output
+            else:
+                assert torch.equal(ya.buf, first[0]) and torch.equal(dxa.buf, first[1]) and torch.equal(stats, first[2]), (flags, rep)
+
+
 @pytest.mark.parametrize("cin,cout,shape,dil,narrow", [
     (64, 128, (2, 64, 32, 32), 2, False),      # DeepLabV3 layer3 / layer4 geometry: 8 rows per tile, 36 staged columns
     (128, 64, (2, 128, 32, 32), 4, True),      # dilation 4: 40 staged columns, 320 staged rows (the A slot exactly), 64-column tiles

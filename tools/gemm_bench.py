@@ -119,6 +119,26 @@ def main():
                             continue
                         f = sorted(v[0] for v in rr[k]); d = sorted(v[1] for v in rr[k])
                         res.append(f"\n   {k:5s} narrow={narrow >> 4}: fwd min {f[0]:6.1f} med {f[len(f)//2]:6.1f} us ({flops/f[0]/1e6:5.0f} TF)  dgrad min {d[0]:6.1f} med {d[len(d)//2]:6.1f} us ({flops/d[0]/1e6:5.0f} TF)")
+        if "flat2" in what:      # the two-work-group build of the flat kernel against the 8-wave one, as the engine launches them
+            from insar_unet_ca_amd._lib import ptr
+            import ctypes as C
+            rr = {}
+            yb = engine.Act.alloc(B, hw, hw, cin, dtype, dev); yb.buf[:, 1:-1, 1:-1].normal_()
+            sc, sh = torch.randn(cin, device=dev), torch.randn(cin, device=dev) * 0.3
+            bs = _lib.InsarBstat(yb.buf.data_ptr(), ptr(sc), ptr(sh))
+            for r in range(3):
+                for nm, fl in (("8-wave persistent", 2 | 4), ("2 x 4-wave persistent", 32 | 4), ("2 x 4-wave per tile", 32)):
+                    rows = call("insar_conv3x3_flat_stat_rows", x.ref, cout, fl)
+                    st = torch.zeros(rows, 2, cout, device=dev)
+                    rowsb = call("insar_conv3x3_flat_stat_rows", g.ref, cin, fl)
+                    stb = torch.zeros(rowsb, 2, cin, device=dev)
+                    rr.setdefault(nm, []).append((
+                        run(lambda: call("insar_conv3x3_flat", x.ref, y.ref, ptr(wf), fl, ptr(st), _lib.stream_ptr())),
+                        run(lambda: call("insar_conv3x3_flat", g.ref, dx.ref, ptr(wd), fl | 1, 0, _lib.stream_ptr())),
+                        run(lambda: call("insar_conv3x3_flat_bstat", g.ref, dx.ref, ptr(wd), fl | 1, ptr(stb), C.byref(bs), _lib.stream_ptr()))))
+            for nm, v in rr.items():
+                best = [min(t[i] for t in v) for i in range(3)]
+                res.append(f"\n   {nm:24s} fwd+stats {best[0]:6.1f} us ({flops/best[0]/1e6:5.0f} TF)  dgrad {best[1]:6.1f} us ({flops/best[1]/1e6:5.0f} TF)  dgrad+bstat {best[2]:6.1f} us ({flops/best[2]/1e6:5.0f} TF)")
         if "flat" in what:
             from insar_unet_ca_amd._lib import ptr
             rows = call("insar_conv3x3_flat_num_mtiles", x.ref)
