@@ -381,8 +381,9 @@ STAT_PREFOLD_ROWS = int(os.environ.get("INSAR_STAT_PREFOLD_ROWS", "1024"))
 FLAT_ROWS = os.environ.get("INSAR_FLAT_ROWS", "1") != "0"
 # flat 3x3 kernel of the 256^2 / 128^2 levels as two co-resident 4-wave work-groups per CU (csrc/conv3x3_flat2.hip: one group's
 # prologue / epilogue under the other's K loop, 128 x 64 wave tiles): 1 = with FLAT_PERSIST's persistent grids (2 per CU),
-# 2 = one work-group per tile, 0 = the 8-wave kernel (results differ by fp32 summation order only)
-FLAT2 = int(os.environ.get("INSAR_FLAT2", "0"))
+# 2 = one work-group per tile, 0 = the 8-wave kernel (results differ by fp32 summation order only). Same box, 150-step runs:
+# 6.963 -> 6.855 ms/step (profiles/r04_flat2.txt)
+FLAT2 = int(os.environ.get("INSAR_FLAT2", "1"))
 BSTAT_FUSE = os.environ.get("INSAR_BSTAT_FUSE", "1") != "0"      # diagnostic: 0 = BatchNorm-backward sums always in a pass of their own
 BSTAT_C64 = os.environ.get("INSAR_BSTAT_C64", "1") != "0"       # the 64 -> 64 kernel's variant of it. Alone it costs more than it saves (8-byte y loads from the accumulator layout: 89 -> 140 us per launch against the 43 us reduce pass it replaces), in the step it wins (same-box A/B 7.70 -> 7.61 ms: one launch less on the dgrad chain beside the weight-gradient stream)
 WGRAD_LATE = os.environ.get("INSAR_WGRAD_ORDER", "before") == "after"      # diagnostic / tuning switch, see ConvBN.backward

@@ -1,6 +1,8 @@
 """Timeline of the last full training step in a rocprofv3 --kernel-trace CSV of bench.py: wall span, busy time of the
 main and the weight-gradient queue, their overlap, GPU idle time, and the kernel-time sums of the forward pass and of
-the rest of the step. usage: timeline.py kernel_trace.csv"""
+the rest of the step. usage: timeline.py kernel_trace.csv [--list REGEX]
+--list: every launch of the step whose kernel name matches, in launch order: queue, start within the step, duration averaged
+over the complete steps of the trace, and how much of it overlapped a kernel of the other queue (last step)."""
 import collections, csv, re, sys
 
 
@@ -58,5 +60,30 @@ def main():
         print(f"  {k:64s} {q:4s} {1e-3 * v[0]:8.1f} us  n={v[1]}")
 
 
+def listing(pattern):
+    rows = list(csv.DictReader(open(sys.argv[1])))
+    for r in rows:
+        r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        r["n"] = re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0]
+    rows.sort(key=lambda r: r["s"])
+    adam = [i for i, r in enumerate(rows) if r["n"].startswith("adam_kernel")]
+    steps = [rows[adam[i] + 1:adam[i + 1] + 1] for i in range(len(adam) - 1)]
+    steps = [st for st in steps if len(st) == len(steps[-1])]
+    last = steps[-1]
+    mainq = collections.Counter(r["Queue_Id"] for r in last).most_common(1)[0][0]
+    rx = re.compile(pattern)
+    for i, r in enumerate(last):
+        if not rx.search(r["n"]):
+            continue
+        durs = [st[i]["e"] - st[i]["s"] for st in steps if st[i]["n"] == r["n"]]
+        other = [(o["s"], o["e"]) for o in last if (o["Queue_Id"] == mainq) != (r["Queue_Id"] == mainq)]
+        ov = sum(max(0, min(r["e"], e) - max(r["s"], s)) for s, e in other)
+        print(f"  {i:4d} {'main' if r['Queue_Id'] == mainq else 'side'} +{1e-3 * (r['s'] - last[0]['s']):8.1f} us  "
+              f"{1e-3 * sum(durs) / len(durs):7.1f} us (n={len(durs)})  beside the other queue {100.0 * ov / max(1, r['e'] - r['s']):3.0f} %  {r['n'][:70]}")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[2] == "--list":
+        listing(sys.argv[3])
+        sys.exit(0)
     main()
