@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INSAR_HIP_LIB") or os.path.join(_HERE, "libinsar_hip.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 IGEMM_OOB_ZERO = 1
 IGEMM_PINGPONG = 2
 
@@ -99,6 +99,7 @@ _SIGNATURES = {
     "insar_conv3x3_flat_ok": [_AP, _I],
     "insar_conv3x3_flat_num_mtiles": [_AP],
     "insar_conv3x3_flat_rows_ok": [_AP, _I],
+    "insar_conv3x3_flat2_rows_ok": [_AP, _I],
     "insar_conv3x3_flat_rows_dil_ok": [_AP, _I, _I],
     "insar_conv3x3_flat_stat_rows": [_AP, _I, _I],
     "insar_conv3x3_flat": [_AP, _AP, _P, _I, _P, _P],
@@ -225,7 +226,7 @@ def load():
     return lib
 
 
-_COUNT_ONLY = {"insar_tune_get", "insar_igemm_num_mtiles", "insar_igemm_tile_rows", "insar_igemm_tile_cols", "insar_igemm_tile_cols_dt", "insar_wgrad_tile", "insar_wgrad_tile_pair", "insar_wgrad_conv3_tile", "insar_wgrad_conv3x_tile", "insar_wgrad_conv3k_tile", "insar_wgrad_conv3k_slices", "insar_conv3x3_flat_ok", "insar_conv3x3_flat_rows_ok", "insar_conv3x3_flat_rows_dil_ok", "insar_conv3x3_flat_num_mtiles", "insar_conv3x3_flat_stat_rows", "insar_conv3x3_c64_ok", "insar_conv3x3_c64_rows", "insar_conv3x3_c64_geometry", "insar_conv3x3_small_wgrad_blocks", "insar_conv3x3_small_wgrad_fused_ok", "insar_conv3x3_small_fwd_rows", "insar_conv1x1_out_bwd_blocks",
+_COUNT_ONLY = {"insar_tune_get", "insar_igemm_num_mtiles", "insar_igemm_tile_rows", "insar_igemm_tile_cols", "insar_igemm_tile_cols_dt", "insar_wgrad_tile", "insar_wgrad_tile_pair", "insar_wgrad_conv3_tile", "insar_wgrad_conv3x_tile", "insar_wgrad_conv3k_tile", "insar_wgrad_conv3k_slices", "insar_conv3x3_flat_ok", "insar_conv3x3_flat_rows_ok", "insar_conv3x3_flat2_rows_ok", "insar_conv3x3_flat_rows_dil_ok", "insar_conv3x3_flat_num_mtiles", "insar_conv3x3_flat_stat_rows", "insar_conv3x3_c64_ok", "insar_conv3x3_c64_rows", "insar_conv3x3_c64_geometry", "insar_conv3x3_small_wgrad_blocks", "insar_conv3x3_small_wgrad_fused_ok", "insar_conv3x3_small_fwd_rows", "insar_conv1x1_out_bwd_blocks",
                "insar_ce_blocks", "insar_conv7x7s2_fwd_rows", "insar_conv7x7s2_wgrad_blocks"}
 
 

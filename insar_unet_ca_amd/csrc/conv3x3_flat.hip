@@ -593,12 +593,15 @@ extern "C" int insar_conv3x3_flat_rows_ok(const InsarAct* x, int32_t N) {
 extern "C" int insar_conv3x3_flat_rows_dil_ok(const InsarAct* x, int32_t N, int32_t dil) {
   return (x && (N % 64) == 0 && (x->c_len % 64) == 0 && flat_rows_geometry(*x, dil)) ? 1 : 0;
 }
+extern "C" int insar_conv3x3_flat2_rows_ok(const InsarAct* x, int32_t N) {
+  return (x && (N % 64) == 0 && (x->c_len % 32) == 0 && insar_flat2_rows_geometry(*x)) ? 1 : 0;
+}
 // Rows of the statistics slab a launch with these flags writes: one per M tile, or — persistent work-groups (flip bit 2)
 // with one N tile — one per work-group.
 extern "C" int insar_conv3x3_flat_stat_rows(const InsarAct* x, int32_t N, int32_t flip) {
   if (!x) return 0;
   const int mt = (flip & 8) ? (int)(((long long)x->B * x->H * x->W) / FL_BM) : flat_mtiles(flat_pixels(*x));
-  if (!(flip & 4) || (flip & 8)) return mt;
+  if (!(flip & 4) || ((flip & 8) && !(flip & 32))) return mt;      // (the two-work-group kernel's row tiles have a persistent form)
   const int bn = ((N % 128) == 0 && !(flip & 16)) ? 128 : 64;
   const int cus = (flip & 32) ? insar_flat2_persistent_grid() : (insar_num_cus() & ~7);      // bit 5: two work-groups per CU
   const long long grid = (long long)mt * (N / bn);
@@ -661,12 +664,19 @@ static int flat_impl(const InsarAct* x, const InsarAct* y, const void* w, int32_
   hipStream_t s = (hipStream_t)stream;
   const bool wide = (a.N % 128) == 0 && !(flip & 16);      // bit 4: 64-column tiles whatever N (grids of 256 work-groups on the 16^2 level)
   a.dil = 1;
+  if ((flip & 8) && (flip & 32)) {      // row tiles of the two-work-group kernel (conv3x3_flat2.hip): W = 128 / 256
+    if (!insar_flat2_rows_geometry(*x)) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: the two-work-group kernel's row tiles need bf16, W = 128 or 256 and H a multiple of 256 / W (got %d x %d)", x->H, x->W);
+    if ((flip >> 8) & 15) INSAR_FAIL(INSAR_E_ARG, "insar_conv3x3_flat: the two-work-group kernel has no dilated form");
+    a.num_mtiles = (int)(((long long)x->B * x->H * x->W) / FL_BM);
+    while ((1 << a.lw) < x->W) ++a.lw;
+    return insar_flat2_launch(a, wide ? 128 : 64, a.by != nullptr, true, s);
+  }
   if (flip & 8) {       // row tiles (bf16, ping-pong loop)
     a.dil = ((flip >> 8) & 15) ? ((flip >> 8) & 15) : 1;
     if (!flat_rows_geometry(*x, a.dil)) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: row tiles need bf16, W a power of two in 16..256, H a multiple of 256 / W and 256 / W * (W + 2 * dilation) <= 320 (got %d x %d, dilation %d)", x->H, x->W, a.dil);
     // the channel conditions insar_conv3x3_flat_rows_ok / _dil_ok promise, re-checked for a direct caller of the C ABI
     if (x->c_len % 64 || y->c_len % 64) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: row tiles need K and N multiples of 64 (got %d, %d)", x->c_len, y->c_len);
-    if (flip & (4 | 32)) INSAR_FAIL(INSAR_E_ARG, "insar_conv3x3_flat: row tiles (flip bit 3) have no persistent (bit 2) or two-work-group (bit 5) form");
+    if (flip & 4) INSAR_FAIL(INSAR_E_ARG, "insar_conv3x3_flat: the 8-wave kernel's row tiles (flip bit 3 without bit 5) have no persistent form (flip bit 2)");
     a.num_mtiles = (int)(((long long)x->B * x->H * x->W) / FL_BM);
     a.lw = 0;
     while ((1 << a.lw) < x->W) ++a.lw;
@@ -679,7 +689,7 @@ static int flat_impl(const InsarAct* x, const InsarAct* y, const void* w, int32_
   }
   if (flip & 32) {      // two co-resident 4-wave work-groups per CU (conv3x3_flat2.hip): bf16, flat geometry
     if (x->dtype != INSAR_BF16) INSAR_FAIL(INSAR_E_DTYPE, "insar_conv3x3_flat: the two-work-group kernel (flip bit 5) is bf16 only");
-    return insar_flat2_launch(a, wide ? 128 : 64, a.by != nullptr, s);
+    return insar_flat2_launch(a, wide ? 128 : 64, a.by != nullptr, false, s);
   }
   if (a.by) {           // bf16: the ping-pong loop whatever the flag says (same results bit for bit)
     if (x->dtype == INSAR_BF16) return wide ? launch_flat<bf16_t, 128, true, true>(a, s) : launch_flat<bf16_t, 64, true, true>(a, s);

@@ -33,7 +33,7 @@ typedef __attribute__((ext_vector_type(4))) float f2_f32x4_t;
 #define F2_THREADS 256
 #define F2_ROWB 64
 
-template <int BN>
+template <int BN, int GEO = 0>
 struct Flat2Cfg {
   static constexpr int NBS = 3;                            // weight slots (one per tap of a dy group)
   static constexpr int A_SLOT = F2_BM * F2_ROWB;           // 16 KB
@@ -76,9 +76,15 @@ __device__ __forceinline__ void f2_wait_and_barrier() {
 }
 __device__ __forceinline__ int f2_swz(int row) { return ((row >> 2) & 1) << 1; }
 
-template <int BN, bool BS>
+// GEO 1, "row tiles" of the 256- and 128-pixel-wide levels: a tile is 256 REAL output pixels = 256 / W whole image rows, and
+// the A slot holds exactly those 256 pixels (of the image row dy - 1 .. dy + 1 above / below): the halo pixel either side of
+// an image row is zero in memory, so it is not staged — the one fragment per dx = -1 / +1 step whose lane 0 / lane 15 would
+// read it (the first / last 16 pixels of an image row) has that lane's registers cleared instead (4 v_and). No halo pixel is
+// computed, the tile count is M / 256 — 1024 / 4096 tiles at B = 16 where the flat geometry's 254-pixel step gives
+// 1065 / 4194: exactly 2 / 8 tiles for each of the 512 persistent work-groups instead of 3 / 9 for the unlucky ones.
+template <int BN, bool BS, int GEO>
 __global__ __launch_bounds__(F2_THREADS, 2) void conv3x3_flat2_kernel(FlatArgs a) {
-  using Cfg = Flat2Cfg<BN>;
+  using Cfg = Flat2Cfg<BN, GEO>;
   constexpr int CH = 8, NT = 4;
   constexpr int WGM = BN == 128 ? 2 : 4;                  // waves along the pixel dimension
   constexpr int WROWS = F2_BM / WGM, MT = WROWS / 16;     // 128 x 64 (8 x 4 MFMA tiles) / 64 x 64 (4 x 4) per wave
@@ -114,10 +120,16 @@ __global__ __launch_bounds__(F2_THREADS, 2) void conv3x3_flat2_kernel(FlatArgs a
   int aBase[3];                                                         // byte offset in smem of this lane's fragment row, per dx
 #pragma unroll
   for (int dxi = 0; dxi < 3; ++dxi) {
-    const int R = wm * WROWS + r16 + dxi - 1;                           // -1 .. 256: rows 0 / 255 of a tile are neighbours only
+    const int R = wm * WROWS + r16 + dxi - 1;                           // -1 .. 256 (flat: rows 0 / 255 of a tile are neighbours only)
     aBase[dxi] = Cfg::A_BASE + R * F2_ROWB + ((kq ^ f2_swz(R)) << 4);
   }
   const int bBase = (wn * 64 + r16) * F2_ROWB + ((kq ^ f2_swz(r16)) << 4);
+  // row tiles: all ones, or zero in the lane whose dx = -1 / +1 neighbour is the (unstaged, zero) halo pixel of its image row
+  uint32_t keepL = 0xffffffffu, keepR = 0xffffffffu;
+  if constexpr (GEO == 1) {
+    if (r16 == 0 && ((wm * WROWS) & (a.W - 1)) == 0) keepL = 0u;
+    if (r16 == 15 && (((wm + 1) * WROWS) & (a.W - 1)) == 0) keepR = 0u;
+  }
   const int kcs = a.kc_count;                                           // 32-channel slabs
 
 #ifdef INSAR_STAMPS
@@ -134,11 +146,25 @@ __global__ __launch_bounds__(F2_THREADS, 2) void conv3x3_flat2_kernel(FlatArgs a
     }
     const int mtile = t / a.num_ntiles, ntile = t - mtile * a.num_ntiles;
     const int n0 = ntile * BN;
-    const int q0 = mtile * F2_STEP - 1;                                 // tile row r <-> padded pixel q0 + r (P < 2^31: host)
+    const int q0 = mtile * F2_STEP - 1;                                 // flat: tile row r <-> padded pixel q0 + r (P < 2^31: host)
+    int prow0 = 0;                                                      // row tiles: padded row of the tile's first image row
+    if constexpr (GEO == 1) {
+      const int hw = a.H * a.W;
+      const int m0 = mtile * F2_BM;
+      const int n0i = m0 / hw;
+      prow0 = n0i * (a.H + 2) + ((m0 - n0i * hw) >> a.lw) + 1;
+    }
 
     int a_off[AD];                                                      // lane offset of this thread's staged pixels (dy = 0)
 #pragma unroll
-    for (int i = 0; i < AD; ++i) a_off[i] = (q0 + srow + 64 * i) * xpitch + xlo;
+    for (int i = 0; i < AD; ++i) {
+      if constexpr (GEO == 1) {
+        const int m = srow + 64 * i;                                    // pixel m of the tile: image row m / W, column m % W
+        a_off[i] = ((prow0 + (m >> a.lw)) * Wp + (m & (a.W - 1)) + 1) * xpitch + xlo;
+      } else {
+        a_off[i] = (q0 + srow + 64 * i) * xpitch + xlo;
+      }
+    }
     const char* wtile = a.w + (long long)n0 * a.K * 2;
 
     auto stageA = [&](int slot, int kc, int dyi) {
@@ -147,7 +173,7 @@ __global__ __launch_bounds__(F2_THREADS, 2) void conv3x3_flat2_kernel(FlatArgs a
 #pragma unroll
       for (int i = 0; i < AD; ++i) {
         int off = a_off[i] + shift;
-        off = off < xlo ? xlo : (off > xhi ? xhi : off);                // the first / last tile reach beyond the buffer: clamp
+        if constexpr (GEO == 0) off = off < xlo ? xlo : (off > xhi ? xhi : off);     // the first / last tile reach beyond the buffer: clamp
         f2_dma(sb, (uint32_t)off, ldsA + slot * Cfg::A_SLOT + i * (F2_THREADS * 16));
       }
     };
@@ -158,6 +184,11 @@ __global__ __launch_bounds__(F2_THREADS, 2) void conv3x3_flat2_kernel(FlatArgs a
       for (int i = 0; i < BD; ++i) f2_dma(sb, w_off[i], ldsB + slot * Cfg::B_SLOT + i * (F2_THREADS * 16));
     };
     auto fill_row_out = [&]() {
+      if constexpr (GEO == 1) {                                         // every row of a row tile is a real output pixel
+        const int ir = tid >> a.lw, wcol = tid & (a.W - 1);
+        rowOut[tid] = ((long long)(prow0 + ir) * Wp + wcol + 1) * a.Cy + a.cy_off;
+        return;
+      }
       const int q = q0 + tid;
       long long ro = -1;
       if (tid >= 1 && tid <= F2_STEP && q >= 0 && q <= Pm1) {
@@ -210,6 +241,10 @@ __global__ __launch_bounds__(F2_THREADS, 2) void conv3x3_flat2_kernel(FlatArgs a
           const char* pa = smem + aBase[dxi] + aslot;
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) xf[mt] = *(const uint4*)(pa + mt * 16 * F2_ROWB);
+          if constexpr (GEO == 1) {
+            if (dxi == 0) { xf[0].x &= keepL; xf[0].y &= keepL; xf[0].z &= keepL; xf[0].w &= keepL; }
+            if (dxi == 2) { xf[MT - 1].x &= keepR; xf[MT - 1].y &= keepR; xf[MT - 1].z &= keepR; xf[MT - 1].w &= keepR; }
+          }
           __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
@@ -358,12 +393,12 @@ __global__ __launch_bounds__(F2_THREADS, 2) void conv3x3_flat2_kernel(FlatArgs a
 // ---- host side -----------------------------------------------------------------------------------
 int insar_flat2_persistent_grid() { return 2 * (insar_num_cus() & ~7); }
 
-template <int BN, bool BS>
+template <int BN, bool BS, int GEO>
 static int launch_flat2(FlatArgs& a, hipStream_t s) {
-  using Cfg = Flat2Cfg<BN>;
+  using Cfg = Flat2Cfg<BN, GEO>;
   static std::atomic<uint64_t> attr_mask{0};
   {
-    hipError_t e = insar_set_lds_once(attr_mask, (const void*)conv3x3_flat2_kernel<BN, BS>, Cfg::LDS_BYTES);
+    hipError_t e = insar_set_lds_once(attr_mask, (const void*)conv3x3_flat2_kernel<BN, BS, GEO>, Cfg::LDS_BYTES);
     if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_conv3x3_flat: hipFuncSetAttribute(%d bytes LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
   }
   a.kc_count = a.K / 32;
@@ -375,16 +410,25 @@ static int launch_flat2(FlatArgs& a, hipStream_t s) {
     const int slots = insar_flat2_persistent_grid();
     if (slots >= 16 && grid > slots) { grid = slots; a.carry = a.num_ntiles == 1 ? 1 : 0; }
   }
-  hipLaunchKernelGGL((conv3x3_flat2_kernel<BN, BS>), dim3((unsigned)grid), dim3(F2_THREADS), Cfg::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((conv3x3_flat2_kernel<BN, BS, GEO>), dim3((unsigned)grid), dim3(F2_THREADS), Cfg::LDS_BYTES, s, a);
   INSAR_CHECK_LAUNCH("insar_conv3x3_flat");
   return INSAR_OK;
 }
 
-int insar_flat2_launch(FlatArgs& a, int bn, bool bstat, hipStream_t s) {
+bool insar_flat2_rows_geometry(const InsarAct& x) {
+  return x.dtype == INSAR_BF16 && (x.W == 128 || x.W == 256) && x.H % (F2_BM / x.W) == 0 &&
+         (long long)x.B * (x.H + 2) * (x.W + 2) < 0x7fffffffLL;
+}
+
+int insar_flat2_launch(FlatArgs& a, int bn, bool bstat, bool rows, hipStream_t s) {
   if (a.K % 32) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: K=%d must be a multiple of 32", a.K);
   // the kernel's 32-bit lane offsets: the activation view and the weight tile must stay below 2 GB
   if ((long long)a.P * a.Cx * 2 >= 0x7fffffffLL || (long long)bn * a.K * 2 >= 0x7fffffffLL)
     INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: activation buffer too large for the two-work-group kernel");
-  if (bn == 128) return bstat ? launch_flat2<128, true>(a, s) : launch_flat2<128, false>(a, s);
-  return bstat ? launch_flat2<64, true>(a, s) : launch_flat2<64, false>(a, s);
+  if (rows) {
+    if (bn == 128) return bstat ? launch_flat2<128, true, 1>(a, s) : launch_flat2<128, false, 1>(a, s);
+    return bstat ? launch_flat2<64, true, 1>(a, s) : launch_flat2<64, false, 1>(a, s);
+  }
+  if (bn == 128) return bstat ? launch_flat2<128, true, 0>(a, s) : launch_flat2<128, false, 0>(a, s);
+  return bstat ? launch_flat2<64, true, 0>(a, s) : launch_flat2<64, false, 0>(a, s);
 }

@@ -380,9 +380,10 @@ STAT_PREFOLD_ROWS = int(os.environ.get("INSAR_STAT_PREFOLD_ROWS", "1024"))
 # 12-24 % faster per launch, tools/gemm_bench.py --what rows -> profiles/r03_row_tiles.txt). 0 = per-tap kernel everywhere.
 FLAT_ROWS = os.environ.get("INSAR_FLAT_ROWS", "1") != "0"
 # flat 3x3 kernel of the 256^2 / 128^2 levels as two co-resident 4-wave work-groups per CU (csrc/conv3x3_flat2.hip: one group's
-# prologue / epilogue under the other's K loop, 128 x 64 wave tiles): 1 = with FLAT_PERSIST's persistent grids (2 per CU),
-# 2 = one work-group per tile, 0 = the 8-wave kernel (results differ by fp32 summation order only). Same box, 150-step runs:
-# 6.963 -> 6.855 ms/step (profiles/r04_flat2.txt)
+# prologue / epilogue under the other's K loop, 128 x 64 wave tiles), persistent grids of two groups per CU (FLAT_PERSIST):
+# 1 = its row tiles where the grid is 128 / 256 pixels wide (M / 256 tiles: the persistent groups get equal shares), the flat
+# geometry elsewhere; 3 = the flat geometry everywhere; 2 = flat geometry, one work-group per tile; 0 = the 8-wave kernel
+# (results differ by fp32 summation order only). Same box, 150-step runs, 0 -> 3: 6.963 -> 6.855 ms/step (profiles/r04_flat2.txt)
 FLAT2 = int(os.environ.get("INSAR_FLAT2", "1"))
 BSTAT_FUSE = os.environ.get("INSAR_BSTAT_FUSE", "1") != "0"      # diagnostic: 0 = BatchNorm-backward sums always in a pass of their own
 BSTAT_C64 = os.environ.get("INSAR_BSTAT_C64", "1") != "0"       # the 64 -> 64 kernel's variant of it. Alone it costs more than it saves (8-byte y loads from the accumulator layout: 89 -> 140 us per launch against the 43 us reduce pass it replaces), in the step it wins (same-box A/B 7.70 -> 7.61 ms: one launch less on the dgrad chain beside the weight-gradient stream)
@@ -444,7 +445,8 @@ def _flat_persist(flip: int) -> bool:
 def _flat_flags(flip: int, x: Act) -> int:
     """flip bits of a flat-geometry launch: bit 2 persistent work-groups, bit 5 the two-work-group kernel (bf16)."""
     two = FLAT2 and x.code == _lib.BF16
-    return (32 if two else 0) | (4 if (_flat_persist(flip) and not (two and FLAT2 == 2)) else 0)
+    rows = two and FLAT2 == 1 and call("insar_conv3x3_flat2_rows_ok", x.ref, 64)
+    return (32 if two else 0) | (8 if rows else 0) | (4 if (_flat_persist(flip) and not (two and FLAT2 == 2)) else 0)
 
 
 def _rows_flags(x: Act, N: int) -> int:
@@ -473,7 +475,7 @@ def _conv3x3_flat(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[to
                                                    128 if (y.c_len % 128 == 0 and not (geo & 16)) else 64,
                                                    (" row tiles" + (" dilated" if geo >> 8 else "")) if geo else "", " +bstat" if bstat is not None else "")
         if flags & 32:
-            tag = "conv3x3_flat2_kernel<%d, %s>" % (128 if y.c_len % 128 == 0 else 64, "true" if bstat is not None else "false")
+            tag = "conv3x3_flat2_kernel<%d, %s, %d>" % (128 if y.c_len % 128 == 0 else 64, "true" if bstat is not None else "false", (flags >> 3) & 1)
         PROFILER.run(tag, flops, fn)
         return
     fn()

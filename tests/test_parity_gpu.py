@@ -365,10 +365,15 @@ def test_conv3x3_flat_against_float64(dev, dtype, cin, cout, shape):
     (32, 64, (3, 32, 30, 30)),       # one slab: the loop is its tail only; tiles straddle image boundaries
     (128, 128, (4, 128, 128, 128)),  # the 128^2 level's shape: more tiles than persistent work-groups (carried sums)
     (256, 128, (1, 256, 32, 32)),    # eight slabs per tap
+    (64, 128, (3, 64, 4, 128)),      # row tiles, W = 128: two image rows per tile, every wave's pixels one image row
+    (128, 64, (2, 128, 3, 256)),     # row tiles, W = 256, 64-column tiles: one image row per tile, four waves along it
+    (64, 64, (10, 64, 128, 128)),    # row tiles: 640 tiles for 512 persistent work-groups (carried sums, uneven shares)
 ])
 def test_conv3x3_flat_two_work_group_kernel_against_float64(dev, cin, cout, shape):
     """csrc/conv3x3_flat2.hip (flip bit 5: two co-resident 4-wave work-groups per CU, 32-channel slabs, 128 x 64 wave tiles),
-    one tile per work-group and persistent (bit 2): forward with BatchNorm partial sums and input gradient against float64,
+    one tile per work-group and persistent (bit 2), in the flat geometry and — where the grid is 128 / 256 pixels wide — as row
+    tiles (bit 3: the halo pixels are not staged, the edge lanes' fragments are cleared): forward with BatchNorm partial sums and
+    input gradient against float64,
     zero halos, against the 8-wave kernel to bf16 rounding of its fp32 sums (the summation order differs), and bit for bit
     run to run over 10 launches each (the second work-group of a CU runs beside the first: a race screen too)."""
     from insar_unet_ca_amd import _lib, engine
@@ -387,8 +392,11 @@ def test_conv3x3_flat_two_work_group_kernel_against_float64(dev, cin, cout, shap
     y8 = engine.Act.alloc(b, h, w, cout, dtype, dev)
     if cin % 64 == 0:
         call("insar_conv3x3_flat", xa.ref, y8.ref, ptr(gw.fwd()), 2, 0, _lib.stream_ptr())
-    for flags in (32, 32 | 4):
+    rows_ok = call("insar_conv3x3_flat2_rows_ok", xa.ref, cout)
+    assert rows_ok == (1 if w in (128, 256) else 0)
+    for flags in (32, 32 | 4) + ((32 | 8, 32 | 8 | 4) if rows_ok else ()):
         first = None
+        rows = b * h * w // 256 if flags & 8 else call("insar_conv3x3_flat_num_mtiles", xa.ref)
         for rep in range(10):
             ya = engine.Act.alloc(b, h, w, cout, dtype, dev)
             dxa = engine.Act.alloc(b, h, w, cin, dtype, dev)
