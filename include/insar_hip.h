@@ -160,8 +160,8 @@ int insar_conv3x3_flat_rows_ok(const InsarAct* x, int32_t N);
 int insar_conv3x3_flat_rows_dil_ok(const InsarAct* x, int32_t N, int32_t dil);
 /* flip bit 5 = 32 (bf16; K a multiple of 32, N of 64): the kernel built as TWO co-resident 4-wave work-groups per CU
  * (csrc/conv3x3_flat2.hip: 32-channel K slabs, 128 x 64 wave tiles; one group's prologue / epilogue under the other's K loop).
- * Flat geometry, or with bit 3 row tiles of the 128- / 256-pixel-wide grids (insar_conv3x3_flat2_rows_ok; the halo pixels are
- * not staged); bit 2 = persistent work-groups (two per CU) in both geometries. Results equal the 8-wave kernel's up to fp32
+ * Flat geometry, or with bit 3 row tiles (W a power of two in 16..256, H a multiple of 256 / W: insar_conv3x3_flat2_rows_ok;
+ * the halo pixels are not staged); bit 2 = persistent work-groups (two per CU) in both geometries. Results equal the 8-wave kernel's up to fp32
  * summation order (channels are added 32 by 32 instead of 64 by 64 per tap). Dilation bits with bit 5: INSAR_E_ARG. */
 int insar_conv3x3_flat2_rows_ok(const InsarAct* x, int32_t N);
 /* rows of the statistics slab for a launch with these flags: one per M tile, or one per work-group for persistent

@@ -664,8 +664,8 @@ static int flat_impl(const InsarAct* x, const InsarAct* y, const void* w, int32_
   hipStream_t s = (hipStream_t)stream;
   const bool wide = (a.N % 128) == 0 && !(flip & 16);      // bit 4: 64-column tiles whatever N (grids of 256 work-groups on the 16^2 level)
   a.dil = 1;
-  if ((flip & 8) && (flip & 32)) {      // row tiles of the two-work-group kernel (conv3x3_flat2.hip): W = 128 / 256
-    if (!insar_flat2_rows_geometry(*x)) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: the two-work-group kernel's row tiles need bf16, W = 128 or 256 and H a multiple of 256 / W (got %d x %d)", x->H, x->W);
+  if ((flip & 8) && (flip & 32)) {      // row tiles of the two-work-group kernel (conv3x3_flat2.hip)
+    if (!insar_flat2_rows_geometry(*x)) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: the two-work-group kernel's row tiles need bf16, W a power of two in 16..256 and H a multiple of 256 / W (got %d x %d)", x->H, x->W);
     if ((flip >> 8) & 15) INSAR_FAIL(INSAR_E_ARG, "insar_conv3x3_flat: the two-work-group kernel has no dilated form");
     a.num_mtiles = (int)(((long long)x->B * x->H * x->W) / FL_BM);
     while ((1 << a.lw) < x->W) ++a.lw;

@@ -76,10 +76,11 @@ __device__ __forceinline__ void f2_wait_and_barrier() {
 }
 __device__ __forceinline__ int f2_swz(int row) { return ((row >> 2) & 1) << 1; }
 
-// GEO 1, "row tiles" of the 256- and 128-pixel-wide levels: a tile is 256 REAL output pixels = 256 / W whole image rows, and
+// GEO 1, "row tiles" (W a power of two in 16 .. 256): a tile is 256 REAL output pixels = 256 / W whole image rows, and
 // the A slot holds exactly those 256 pixels (of the image row dy - 1 .. dy + 1 above / below): the halo pixel either side of
 // an image row is zero in memory, so it is not staged — the one fragment per dx = -1 / +1 step whose lane 0 / lane 15 would
-// read it (the first / last 16 pixels of an image row) has that lane's registers cleared instead (4 v_and). No halo pixel is
+// read it (the first / last 16 pixels of an image row) has that lane's registers cleared instead (4 v_and; at W >= 128 one
+// fragment per wave and step, at W = 16 every fragment). No halo pixel is
 // computed, the tile count is M / 256 — 1024 / 4096 tiles at B = 16 where the flat geometry's 254-pixel step gives
 // 1065 / 4194: exactly 2 / 8 tiles for each of the 512 persistent work-groups instead of 3 / 9 for the unlucky ones.
 template <int BN, bool BS, int GEO>
@@ -124,11 +125,16 @@ __global__ __launch_bounds__(F2_THREADS, 2) void conv3x3_flat2_kernel(FlatArgs a
     aBase[dxi] = Cfg::A_BASE + R * F2_ROWB + ((kq ^ f2_swz(R)) << 4);
   }
   const int bBase = (wn * 64 + r16) * F2_ROWB + ((kq ^ f2_swz(r16)) << 4);
-  // row tiles: all ones, or zero in the lane whose dx = -1 / +1 neighbour is the (unstaged, zero) halo pixel of its image row
-  uint32_t keepL = 0xffffffffu, keepR = 0xffffffffu;
+  // row tiles: the lane whose dx = -1 / +1 neighbour is the (unstaged, zero) halo pixel of its image row — lane 0 / 15 of the
+  // 16-pixel fragments that begin / end an image row (bit mt of edgeL / edgeR; W >= 16: a fragment never straddles two rows)
+  const uint32_t keepL = r16 == 0 ? 0u : 0xffffffffu, keepR = r16 == 15 ? 0u : 0xffffffffu;
+  uint32_t edgeL = 0, edgeR = 0;
   if constexpr (GEO == 1) {
-    if (r16 == 0 && ((wm * WROWS) & (a.W - 1)) == 0) keepL = 0u;
-    if (r16 == 15 && (((wm + 1) * WROWS) & (a.W - 1)) == 0) keepR = 0u;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (((wm * WROWS + mt * 16) & (a.W - 1)) == 0) edgeL |= 1u << mt;
+      if (((wm * WROWS + mt * 16 + 16) & (a.W - 1)) == 0) edgeR |= 1u << mt;
+    }
   }
   const int kcs = a.kc_count;                                           // 32-channel slabs
 
@@ -242,8 +248,12 @@ __global__ __launch_bounds__(F2_THREADS, 2) void conv3x3_flat2_kernel(FlatArgs a
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) xf[mt] = *(const uint4*)(pa + mt * 16 * F2_ROWB);
           if constexpr (GEO == 1) {
-            if (dxi == 0) { xf[0].x &= keepL; xf[0].y &= keepL; xf[0].z &= keepL; xf[0].w &= keepL; }
-            if (dxi == 2) { xf[MT - 1].x &= keepR; xf[MT - 1].y &= keepR; xf[MT - 1].z &= keepR; xf[MT - 1].w &= keepR; }
+            if (dxi != 1) {
+              const uint32_t edge = dxi == 0 ? edgeL : edgeR, keep = dxi == 0 ? keepL : keepR;
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt)
+                if (edge & (1u << mt)) { xf[mt].x &= keep; xf[mt].y &= keep; xf[mt].z &= keep; xf[mt].w &= keep; }
+            }
           }
           __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -416,7 +426,7 @@ static int launch_flat2(FlatArgs& a, hipStream_t s) {
 }
 
 bool insar_flat2_rows_geometry(const InsarAct& x) {
-  return x.dtype == INSAR_BF16 && (x.W == 128 || x.W == 256) && x.H % (F2_BM / x.W) == 0 &&
+  return x.dtype == INSAR_BF16 && x.W >= 16 && x.W <= F2_BM && (x.W & (x.W - 1)) == 0 && x.H % (F2_BM / x.W) == 0 &&
          (long long)x.B * (x.H + 2) * (x.W + 2) < 0x7fffffffLL;
 }
 

@@ -19,7 +19,7 @@ struct FlatArgs {
   const char* by; const float* bscale; const float* bshift;   // BatchNorm-backward sums in the stats slab (InsarBstat)
 };
 
-// conv3x3_flat2.hip: bf16; flat geometry, or (rows) row tiles of the 128- / 256-pixel-wide grids. `a` as flat_impl fills it;
+// conv3x3_flat2.hip: bf16; flat geometry, or (rows) row tiles (W = 2^k in 16 .. 256). `a` as flat_impl fills it;
 // bn = 128 / 64 columns per tile.
 int insar_flat2_launch(FlatArgs& a, int bn, bool bstat, bool rows, hipStream_t s);
 bool insar_flat2_rows_geometry(const InsarAct& x);

@@ -360,7 +360,7 @@ OUTC_WGRAD_FUSE = os.environ.get("INSAR_OUTC_WGRAD_FUSE", "1") != "0"   # diagno
 WGRAD_FILL_T = float(os.environ.get("INSAR_WGRAD_FILL_T", "0.7"))   # the same for the transposed convs' per-tap weight gradient
 WGRAD_FILL_DL = float(os.environ.get("INSAR_WGRAD_FILL_DL", "0.5"))  # ... and for DeepLabV3-CA's per-tap weight gradients (1x1 / dilated / strided convs: most of its side stream; config 5 same-box 0.5 9.32, 0.6 9.42, 0.7 9.51, 0.85 9.60 ms/step)
 WGRAD_FILL_ALONE = float(os.environ.get("INSAR_WGRAD_FILL_ALONE", "1.0"))   # ... and when it has the GPU to itself
-WGRAD_FILL = float(os.environ.get("INSAR_WGRAD_FILL", "0.6"))     # share of the work-group slots a side-stream weight gradient aims at (0.5 until the row tiles made the dgrad chain faster: re-swept, 0.55-0.65 with 0.7 for the transposed convs is 0.09 ms better, profiles/r03_row_tiles.txt)
+WGRAD_FILL = float(os.environ.get("INSAR_WGRAD_FILL", "0.5"))     # share of the work-group slots a side-stream weight gradient aims at. Re-swept whenever the main queue's kernels change: 0.5 in round 2, 0.6 with round 3's row tiles (profiles/r03_row_tiles.txt), 0.5 again with the two-work-group flat kernel (same box, 120-step runs: 0.4 6.85, 0.45 6.80, 0.5 6.74, 0.55 6.79, 0.6 6.79, 0.7 6.80 ms/step; profiles/r04_flat2.txt)
 WGRAD_ROWS = os.environ.get("INSAR_WGRAD_ROWS", "1") != "0"      # diagnostic: 0 = per-tap weight-gradient kernel everywhere
 WGRAD_K = os.environ.get("INSAR_WGRAD_K", "0") != "0"            # 1 = wgrad3k.hip (pixel slices per wave) for the 64 / 128-channel layers named by INSAR_WGRAD_K_TILES. Off: faster alone on two tile shapes, but in the step 6.90 vs 6.915 ms in three interleaved rounds (its KS slabs per work-group cost more fold traffic than the loop saves)
 # (Cin x Cout) tiles that take wgrad3k.hip. Measured (profiles/r04_wgrad3k.txt): alone 128 x 64 182.7 -> 155.8 us, 128 x 128 77.8 -> 72.4,
@@ -459,6 +459,9 @@ def _rows_flags(x: Act, N: int) -> int:
     if call("insar_igemm_tile_cols_dt", M, N, x.code) == 256:
         return 0
     narrow = (N % 128) != 0 or (M // 256) * (N // 128) < 256
+    if FLAT2 == 1 and not narrow and (M // 256) * (N // 128) >= 2 * torch.cuda.get_device_properties(x.buf.device).multi_processor_count and call("insar_conv3x3_flat2_rows_ok", x.ref, N):
+        # enough 128-column tiles for two work-groups per CU: the two-work-group kernel's row tiles, persistent
+        return 8 | 32 | (4 if FLAT_PERSIST else 0)
     return 8 | (16 if narrow else 0)
 
 
@@ -473,7 +476,7 @@ def _conv3x3_flat(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[to
         flops = 2.0 * x.B * x.H * x.W * y.c_len * x.c_len * 9
         tag = "conv3x3_flat_kernel<%s, %d>%s%s" % ("float" if x.code == _lib.F32 else "bf16_t",
                                                    128 if (y.c_len % 128 == 0 and not (geo & 16)) else 64,
-                                                   (" row tiles" + (" dilated" if geo >> 8 else "")) if geo else "", " +bstat" if bstat is not None else "")
+                                                   (" row tiles" + (" dilated" if (geo >> 8) & 15 else "")) if geo else "", " +bstat" if bstat is not None else "")
         if flags & 32:
             tag = "conv3x3_flat2_kernel<%d, %s, %d>" % (128 if y.c_len % 128 == 0 else 64, "true" if bstat is not None else "false", (flags >> 3) & 1)
         PROFILER.run(tag, flops, fn)
@@ -936,9 +939,10 @@ class ConvBN:
             elif self.rows_bwd:
                 # row tiles are whole image rows of ONE image: the slab rows group per image, as an SE consumer needs
                 slab = None
+                geo = self.rows_bwd & ~4 if bstat_se else self.rows_bwd      # (persistent work-groups' carried sums mix images)
                 if bstat_for is not None and BSTAT_FUSE and _same_layout(dx, bstat_for.y):
-                    slab = bstat_for.bstat_slab(call("insar_conv3x3_flat_stat_rows", self.dy.ref, self.cin, self.rows_bwd), bstat_se)
-                _conv3x3_flat(self.dy, dx, self.w.dgrad(), 1, slab[0] if slab else None, bstat=slab[1] if slab else None, geo=self.rows_bwd)
+                    slab = bstat_for.bstat_slab(call("insar_conv3x3_flat_stat_rows", self.dy.ref, self.cin, geo), bstat_se)
+                _conv3x3_flat(self.dy, dx, self.w.dgrad(), 1, slab[0] if slab else None, bstat=slab[1] if slab else None, geo=geo)
                 if slab:
                     bstat_for.bred_ready = True
             else:

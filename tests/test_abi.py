@@ -130,11 +130,12 @@ def test_row_tile_geometry_queries():
     x = act(16, 32, 32, 512, BF16)
     for flags in (8, 8 | 16, 8 | 4, 8 | 2 | (2 << 8)):
         assert call("insar_conv3x3_flat_stat_rows", x, 512, flags) == 16 * 32 * 32 // 256
-    # the two-work-group kernel (flip bit 5): row tiles on the 128- / 256-pixel-wide grids only, K in 32s; persistent work-groups
+    # the two-work-group kernel (flip bit 5): row tiles with the same grid conditions, K in 32s; persistent work-groups
     # (bit 2; two per CU) carry the sums: one slab row per work-group where one N tile has more tiles than that
     ok2 = lambda b, h, w, c, n, dt=BF16: call("insar_conv3x3_flat2_rows_ok", act(b, h, w, c, dt), n)
     assert ok2(16, 256, 256, 64, 64) == 1 and ok2(16, 128, 128, 32, 128) == 1 and ok2(2, 2, 128, 64, 64) == 1
-    assert ok2(16, 64, 64, 64, 64) == 0 and ok2(2, 3, 128, 64, 64) == 0 and ok2(16, 128, 128, 48, 64) == 0 and ok2(16, 128, 128, 64, 64, F32) == 0
+    assert ok2(16, 64, 64, 64, 64) == 1 and ok2(16, 16, 16, 1024, 1024) == 1
+    assert ok2(16, 8, 8, 64, 64) == 0 and ok2(2, 3, 128, 64, 64) == 0 and ok2(16, 128, 128, 48, 64) == 0 and ok2(16, 128, 128, 64, 64, F32) == 0
     big = act(16, 128, 128, 128, BF16)
     tiles = 16 * 128 * 128 // 256
     assert call("insar_conv3x3_flat_stat_rows", big, 128, 32 | 8) == tiles

@@ -368,6 +368,9 @@ def test_conv3x3_flat_against_float64(dev, dtype, cin, cout, shape):
     (64, 128, (3, 64, 4, 128)),      # row tiles, W = 128: two image rows per tile, every wave's pixels one image row
     (128, 64, (2, 128, 3, 256)),     # row tiles, W = 256, 64-column tiles: one image row per tile, four waves along it
     (64, 64, (10, 64, 128, 128)),    # row tiles: 640 tiles for 512 persistent work-groups (carried sums, uneven shares)
+    (128, 128, (3, 128, 8, 64)),     # row tiles, W = 64: four image rows per tile, two per wave (two edge fragments a side)
+    (64, 128, (2, 64, 16, 32)),      # row tiles, W = 32: eight image rows per tile
+    (64, 64, (3, 64, 16, 16)),       # row tiles, W = 16: every fragment begins and ends an image row; 64-column tiles
 ])
 def test_conv3x3_flat_two_work_group_kernel_against_float64(dev, cin, cout, shape):
     """csrc/conv3x3_flat2.hip (flip bit 5: two co-resident 4-wave work-groups per CU, 32-channel slabs, 128 x 64 wave tiles),
@@ -393,7 +396,7 @@ def test_conv3x3_flat_two_work_group_kernel_against_float64(dev, cin, cout, shap
     if cin % 64 == 0:
         call("insar_conv3x3_flat", xa.ref, y8.ref, ptr(gw.fwd()), 2, 0, _lib.stream_ptr())
     rows_ok = call("insar_conv3x3_flat2_rows_ok", xa.ref, cout)
-    assert rows_ok == (1 if w in (128, 256) else 0)
+    assert rows_ok == (1 if (w in (16, 32, 64, 128, 256) and h % (256 // w) == 0) else 0)
     for flags in (32, 32 | 4) + ((32 | 8, 32 | 8 | 4) if rows_ok else ()):
         first = None
         rows = b * h * w // 256 if flags & 8 else call("insar_conv3x3_flat_num_mtiles", xa.ref)
