@@ -226,7 +226,7 @@ def measure(args, world: int, rank: int, dev, dist, iu, engine, make_batch):
 
     # Roofline leg: the same K steps twice more, in the same process, with a HIP-event pair around every GEMM-class
     # launch, recorded on the stream the kernel is launched on (main or side). Pass 1 keeps the launch configuration
-    # of the timed region (weight gradients on the side stream beside the dgrad chain, split-K for 0.6 of the work-group slots);
+    # of the timed region (weight gradients on the side stream beside the dgrad chain, split-K for engine.WGRAD_FILL of the work-group slots);
     # pass 2 runs everything on ONE stream (each kernel alone on the chip, split-K that fills it). Both are kept out
     # of the timed region above because ~130 event records per step cost host time and perturb the overlap.
     timers = {}
@@ -360,7 +360,7 @@ def measure(args, world: int, rank: int, dev, dist, iu, engine, make_batch):
                                "avg_launch_us": round(al["avg_us"], 2)} if al else None),
                     "measured": "HIP events around each launch on the stream it is launched on, in a second pass of the "
                                 "same %d steps in the launch configuration of the timed region (weight gradients on the "
-                                "side stream beside the dgrad chain, split-K for 0.6 of the work-group slots: kernels that "
+                                f"side stream beside the dgrad chain, split-K for {engine.WGRAD_FILL:g} of the work-group slots: kernels that "
                                 "overlap share the chip, so their durations are longer than alone; %.2f ms/step with "
                                 "events vs %.2f ms/step timed); `alone` = a third pass on ONE stream, every kernel by "
                                 "itself on the chip (%.2f ms/step); compare profiles/ kernel stats; traffic = rocprofv3 "
@@ -420,8 +420,10 @@ def other_configs(args, dev, dist, iu, engine, make_batch) -> dict:
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: 100 timed steps after 20 (0.8 s of GPU time). 20-step runs scatter by +-0.04 ms/step on one box and read
+    # 0.05-0.07 ms higher than 150- / 400-step runs (profiles/r04_flat2.txt, item 7): clocks and caches are still settling
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=16, help="tiles per GPU (config 2: 16)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -448,7 +450,7 @@ def main() -> int:
                     help="measure although INSAR_* environment switches that select kernels / launch paths are set to non-default "
                          "values (A/B runs); without it such a run exits with code 3. The line reports them under `switches` either way")
     ap.add_argument("--wgrad-fill", type=float, default=None,
-                    help="share of the work-group slots a side-stream weight gradient aims at (engine.WGRAD_FILL, default 0.6; the "
+                    help="share of the work-group slots a side-stream weight gradient aims at (engine.WGRAD_FILL, default 0.5; the "
                          "transposed convs' 0.7 scales with it): the 8-GPU operator's knob for trading side-queue CUs against RCCL's")
     ap.add_argument("--stream-input", action="store_true",
                     help="feed every step from the host: batches in pinned memory, copied on a copy stream while the previous "

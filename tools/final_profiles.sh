@@ -33,7 +33,7 @@ cp $(ls "$OUT"/p2/*/*_kernel_stats.csv | head -n 1) "$OUT/bench_kernel_stats_sin
 cp $(ls "$OUT"/pF/*/*_counter_collection.csv | head -n 1) "$OUT/pmc_fetch.csv"
 cp $(ls "$OUT"/pW/*/*_counter_collection.csv | head -n 1) "$OUT/pmc_write.csv"
 cp $(ls "$OUT"/pT/*/*_kernel_trace.csv | head -n 1) "$OUT/kernel_trace.csv"
-python3 "$R/tools/pmc_traffic.py" "$OUT/pmc_fetch.csv" "$OUT/pmc_write.csv" "$OUT/pmc_traffic.json" "timed region (weight gradients split for 0.6 of the work-group slots, as beside the dgrad chain)" | tee "$OUT/pmc_traffic.txt"
+python3 "$R/tools/pmc_traffic.py" "$OUT/pmc_fetch.csv" "$OUT/pmc_write.csv" "$OUT/pmc_traffic.json" "timed region (weight gradients split for engine.WGRAD_FILL = 0.5 of the work-group slots, as beside the dgrad chain)" | tee "$OUT/pmc_traffic.txt"
 python3 "$R/tools/timeline.py" "$OUT/kernel_trace.csv" | tee "$OUT/timeline.txt"
 rm -rf "$OUT/p1" "$OUT/p2" "$OUT/p3" "$OUT/pF" "$OUT/pW" "$OUT/pT" "$OUT/pmc_fetch.csv" "$OUT/pmc_write.csv"      # keep the summaries only
 fi
