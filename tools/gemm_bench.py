@@ -127,8 +127,9 @@ def main():
             sc, sh = torch.randn(cin, device=dev), torch.randn(cin, device=dev) * 0.3
             bs = _lib.InsarBstat(yb.buf.data_ptr(), ptr(sc), ptr(sh))
             for r in range(3):
-                for nm, fl in (("8-wave persistent", 2 | 4), ("2 x 4-wave persistent", 32 | 4), ("2 x 4-wave row tiles", 32 | 8 | 4)):
-                    if (fl & 8) and not call("insar_conv3x3_flat2_rows_ok", x.ref, cout):
+                for nm, fl in (("8-wave persistent", 2 | 4), ("8-wave row tiles", 2 | 8), ("8-wave row tiles 64-col", 2 | 8 | 16), ("2 x 4-wave persistent", 32 | 4),
+                               ("2 x 4-wave row tiles", 32 | 8 | 4), ("2 x 4-wave row tiles 64-col", 32 | 8 | 4 | 16)):
+                    if (fl & 8) and not (call("insar_conv3x3_flat2_rows_ok", x.ref, cout) and call("insar_conv3x3_flat_rows_ok", x.ref, cout) and call("insar_conv3x3_flat_rows_ok", g.ref, cin)):
                         continue
                     rows = call("insar_conv3x3_flat_stat_rows", x.ref, cout, fl)
                     st = torch.zeros(rows, 2, cout, device=dev)
@@ -140,7 +141,7 @@ def main():
                         run(lambda: call("insar_conv3x3_flat_bstat", g.ref, dx.ref, ptr(wd), fl | 1, ptr(stb), C.byref(bs), _lib.stream_ptr()))))
             for nm, v in rr.items():
                 best = [min(t[i] for t in v) for i in range(3)]
-                res.append(f"\n   {nm:24s} fwd+stats {best[0]:6.1f} us ({flops/best[0]/1e6:5.0f} TF)  dgrad {best[1]:6.1f} us ({flops/best[1]/1e6:5.0f} TF)  dgrad+bstat {best[2]:6.1f} us ({flops/best[2]/1e6:5.0f} TF)")
+                res.append(f"\n   {nm:28s} fwd+stats {best[0]:6.1f} us ({flops/best[0]/1e6:5.0f} TF)  dgrad {best[1]:6.1f} us ({flops/best[1]/1e6:5.0f} TF)  dgrad+bstat {best[2]:6.1f} us ({flops/best[2]/1e6:5.0f} TF)")
         if "flat" in what:
             from insar_unet_ca_amd._lib import ptr
             rows = call("insar_conv3x3_flat_num_mtiles", x.ref)
