@@ -331,14 +331,14 @@ def test_switch_table_is_read_off_the_source(monkeypatch):
     import os
     from insar_unet_ca_amd import switches
     known = switches.declared([os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")])
-    for name, default in (("INSAR_WGRAD_FILL", "0.6"), ("INSAR_TAPE", "1"), ("INSAR_FLAT_PERSIST", "2"), ("INSAR_HIP_LIB", None),
+    for name, default in (("INSAR_WGRAD_FILL", "0.5"), ("INSAR_FLAT2", "1"), ("INSAR_TAPE", "1"), ("INSAR_FLAT_PERSIST", "2"), ("INSAR_HIP_LIB", None),
                           ("INSAR_GATE_FUSE", "1"), ("INSAR_ADAM_CHUNK", "8192"), ("INSAR_MAIN_PRIORITY", None)):
         assert name in known and known[name] == default, (name, known.get(name))
     for k in list(os.environ):
         if k.startswith("INSAR_"):
             monkeypatch.delenv(k)
     assert switches.non_default() == {}
-    monkeypatch.setenv("INSAR_WGRAD_FILL", "0.6")            # the default, spelled out: not a change
+    monkeypatch.setenv("INSAR_WGRAD_FILL", "0.5")            # the default, spelled out: not a change
     monkeypatch.setenv("INSAR_TAPE", "0")
     monkeypatch.setenv("INSAR_FLAT_ROWS", "0")
     monkeypatch.setenv("INSAR_NO_SUCH_SWITCH", "1")
