@@ -106,8 +106,7 @@ __global__ __launch_bounds__(F2_THREADS, 2) void conv3x3_flat2_kernel(FlatArgs a
   const int xpitch = a.Cx * 2;
   const int srow = tid >> 2;                                            // staged row (+ 64 i) of this thread's DMA chunks
   const int schunk = ((tid & 3) ^ f2_swz(srow)) * 16;                   // the source chunk its lane-linear LDS position holds
-  const int xlo = a.cx_off * 2 + schunk;                                // lane offset of pixel 0 / of the last pixel: clamps
-  const int xhi = Pm1 * xpitch + xlo;
+  const int xlo = a.cx_off * 2 + schunk;                                // lane offset inside a pixel (channel slice + this lane's chunk)
   uint32_t w_off[BD];
 #pragma unroll
   for (int i = 0; i < BD; ++i) w_off[i] = (uint32_t)((srow + 64 * i) * a.K * 2 + schunk);
@@ -161,25 +160,36 @@ __global__ __launch_bounds__(F2_THREADS, 2) void conv3x3_flat2_kernel(FlatArgs a
       prow0 = n0i * (a.H + 2) + ((m0 - n0i * hw) >> a.lw) + 1;
     }
 
-    int a_off[AD];                                                      // lane offset of this thread's staged pixels (dy = 0)
+    // Lane offsets are 32-bit and RELATIVE to the tile's lowest staged pixel (scalar 64-bit base): whatever the size of the
+    // activation buffer, a tile spans 256 pixels + an image row either side.
+    const int base_pix = GEO == 1 ? (prow0 - 1) * Wp : (q0 - Wp > 0 ? q0 - Wp : 0);
+    const char* xtile = a.x + (long long)base_pix * xpitch;
+    int a_off[AD];                                                      // this thread's staged pixels (dy = 0)
 #pragma unroll
     for (int i = 0; i < AD; ++i) {
       if constexpr (GEO == 1) {
         const int m = srow + 64 * i;                                    // pixel m of the tile: image row m / W, column m % W
-        a_off[i] = ((prow0 + (m >> a.lw)) * Wp + (m & (a.W - 1)) + 1) * xpitch + xlo;
+        a_off[i] = ((1 + (m >> a.lw)) * Wp + (m & (a.W - 1)) + 1) * xpitch + xlo;
       } else {
-        a_off[i] = (q0 + srow + 64 * i) * xpitch + xlo;
+        a_off[i] = (q0 + srow + 64 * i - base_pix) * xpitch + xlo;
       }
+    }
+    // flat geometry: the first / last tiles reach beyond the buffer — clamp to pixel 0 / P - 1 (relative, saturated far from the ends)
+    int xmin = 0, xmax = 0;
+    if constexpr (GEO == 0) {
+      const long long lo = xlo - (long long)base_pix * xpitch, hi = xlo + (long long)(Pm1 - base_pix) * xpitch;
+      xmin = lo < -(1 << 30) ? -(1 << 30) : (int)lo;
+      xmax = hi > (1 << 30) ? (1 << 30) : (int)hi;
     }
     const char* wtile = a.w + (long long)n0 * a.K * 2;
 
     auto stageA = [&](int slot, int kc, int dyi) {
-      const char* sb = a.x + kc * F2_ROWB;
+      const char* sb = xtile + kc * F2_ROWB;
       const int shift = (dyi - 1) * Wp * xpitch;
 #pragma unroll
       for (int i = 0; i < AD; ++i) {
         int off = a_off[i] + shift;
-        if constexpr (GEO == 0) off = off < xlo ? xlo : (off > xhi ? xhi : off);     // the first / last tile reach beyond the buffer: clamp
+        if constexpr (GEO == 0) off = off < xmin ? xmin : (off > xmax ? xmax : off);
         f2_dma(sb, (uint32_t)off, ldsA + slot * Cfg::A_SLOT + i * (F2_THREADS * 16));
       }
     };
@@ -432,9 +442,10 @@ bool insar_flat2_rows_geometry(const InsarAct& x) {
 
 int insar_flat2_launch(FlatArgs& a, int bn, bool bstat, bool rows, hipStream_t s) {
   if (a.K % 32) INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: K=%d must be a multiple of 32", a.K);
-  // the kernel's 32-bit lane offsets: the activation view and the weight tile must stay below 2 GB
-  if ((long long)a.P * a.Cx * 2 >= 0x7fffffffLL || (long long)bn * a.K * 2 >= 0x7fffffffLL)
-    INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: activation buffer too large for the two-work-group kernel");
+  // 32-bit lane offsets: relative to the tile for the activations (any buffer size), to the N tile for the weights; one tile
+  // spans 256 pixels + an image row either side
+  if ((long long)(F2_BM + 2 * (a.W + 2) + 2) * a.Cx * 2 >= (1LL << 30) || (long long)bn * a.K * 2 >= (1LL << 30))
+    INSAR_FAIL(INSAR_E_SHAPE, "insar_conv3x3_flat: rows too long for the two-work-group kernel's 32-bit tile offsets");
   if (rows) {
     if (bn == 128) return bstat ? launch_flat2<128, true, 1>(a, s) : launch_flat2<128, false, 1>(a, s);
     return bstat ? launch_flat2<64, true, 1>(a, s) : launch_flat2<64, false, 1>(a, s);

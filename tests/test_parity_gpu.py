@@ -424,6 +424,37 @@ def test_conv3x3_flat_two_work_group_kernel_against_float64(dev, cin, cout, shap
                 assert torch.equal(ya.buf, first[0]) and torch.equal(dxa.buf, first[1]) and torch.equal(stats, first[2]), (flags, rep)
 
 
+def test_conv3x3_flat_two_work_group_kernel_beyond_2_gib(dev):
+    """An activation buffer larger than 2^31 bytes (64 x 256 x 256 tiles of 256 channels: 2.18 GB — a batch the 288 GB of one
+    MI355X invite): the two-work-group kernel addresses its operands by a 64-bit tile base + 32-bit lane offsets relative to
+    the tile, in both geometries; checked against the 8-wave kernel (64-bit lane addresses) to one bf16 rounding of the largest
+    output, on the last image too — the one beyond the 2 GiB mark."""
+    from insar_unet_ca_amd import _lib, engine
+    from insar_unet_ca_amd._lib import call, ptr
+    dtype = torch.bfloat16
+    ctx = engine.Ctx(dev, dtype)
+    b, cin, cout, h, w = 64, 256, 64, 256, 256
+    xa = engine.Act.alloc(b, h, w, cin, dtype, dev)
+    assert xa.buf.numel() * 2 > 2 ** 31
+    g = torch.Generator(device=dev).manual_seed(3)
+    for i in range(b):
+        xa.buf[i, 1:-1, 1:-1] = torch.randn(h, w, cin, device=dev, generator=g).to(dtype)
+    p = torch.nn.Parameter(cf.fill_tensor("weight", (cout, cin, 3, 3), 11).to(dev))
+    wf = engine.GemmWeight(ctx, p, "conv3").fwd()
+    ref = engine.Act.alloc(b, h, w, cout, dtype, dev)
+    call("insar_conv3x3_flat", xa.ref, ref.ref, ptr(wf), 2 | 8, 0, _lib.stream_ptr())
+    scale = float(ref.buf.float().abs().max())
+    assert scale > 0
+    for flags in (32 | 4, 32 | 8 | 4, 32 | 8):
+        ya = engine.Act.alloc(b, h, w, cout, dtype, dev)
+        call("insar_conv3x3_flat", xa.ref, ya.ref, ptr(wf), flags, 0, _lib.stream_ptr())
+        for img in (0, b // 2, b - 1):
+            d = float((ya.buf[img].float() - ref.buf[img].float()).abs().max())
+            assert d <= 8e-3 * scale, (flags, img, d, scale)
+        assert _halo_abs(ya) == 0.0
+        del ya
+
+
 @pytest.mark.parametrize("cin,cout,shape,dil,narrow", [
     (64, 128, (2, 64, 32, 32), 2, False),      # DeepLabV3 layer3 / layer4 geometry: 8 rows per tile, 36 staged columns
     (128, 64, (2, 128, 32, 32), 4, True),      # dilation 4: 40 staged columns, 320 staged rows (the A slot exactly), 64-column tiles
