@@ -385,6 +385,7 @@ FLAT_ROWS = os.environ.get("INSAR_FLAT_ROWS", "1") != "0"
 # geometry elsewhere; 3 = the flat geometry everywhere; 2 = flat geometry, one work-group per tile; 0 = the 8-wave kernel
 # (results differ by fp32 summation order only). Same box, 150-step runs, 0 -> 3: 6.963 -> 6.855 ms/step (profiles/r04_flat2.txt)
 FLAT2 = int(os.environ.get("INSAR_FLAT2", "1"))
+FLAT2_PERSIST = int(os.environ.get("INSAR_FLAT2_PERSIST", "1"))   # ... its persistent grids (two work-groups per CU walking their tiles, BatchNorm sums carried): 1 = forward launches only, 2 = all, 0 = never. Beside the weight-gradient stream, whose 156 KB work-groups own whole CUs, a static two-per-CU grid waits for CUs it does not get: one work-group per tile there (same box, 120-step runs: 2 -> 1 6.917 -> 6.850 ms/step, 0 6.848)
 FLAT2_KMAX = int(os.environ.get("INSAR_FLAT2_KMAX", "512"))       # ... its row tiles instead of the per-tap kernel's 256 x 256 tiles up to this many input channels (0 = never)
 BSTAT_FUSE = os.environ.get("INSAR_BSTAT_FUSE", "1") != "0"      # diagnostic: 0 = BatchNorm-backward sums always in a pass of their own
 BSTAT_C64 = os.environ.get("INSAR_BSTAT_C64", "1") != "0"       # the 64 -> 64 kernel's variant of it. Alone it costs more than it saves (8-byte y loads from the accumulator layout: 89 -> 140 us per launch against the 43 us reduce pass it replaces), in the step it wins (same-box A/B 7.70 -> 7.61 ms: one launch less on the dgrad chain beside the weight-gradient stream)
@@ -447,10 +448,15 @@ def _flat_flags(flip: int, x: Act) -> int:
     """flip bits of a flat-geometry launch: bit 2 persistent work-groups, bit 5 the two-work-group kernel (bf16)."""
     two = FLAT2 and x.code == _lib.BF16
     rows = two and FLAT2 == 1 and call("insar_conv3x3_flat2_rows_ok", x.ref, 64)
-    return (32 if two else 0) | (8 if rows else 0) | (4 if (_flat_persist(flip) and not (two and FLAT2 == 2)) else 0)
+    persist = _flat2_persist(flip) if two else _flat_persist(flip)
+    return (32 if two else 0) | (8 if rows else 0) | (4 if (persist and not (two and FLAT2 == 2)) else 0)
 
 
-def _rows_flags(x: Act, N: int, K: Optional[int] = None) -> int:
+def _flat2_persist(flip: int) -> bool:
+    return FLAT2_PERSIST == 2 or (FLAT2_PERSIST == 1 and not (flip & 1))
+
+
+def _rows_flags(x: Act, N: int, K: Optional[int] = None, flip: int = 0) -> int:
     """flip bits (8 | 16) of the flat kernel's row-tile geometry for a 3x3 conv of x's grid to N channels, or 0 where the
     per-tap kernel keeps the layer: fp32, grids the geometry does not cover, and wherever the per-tap kernel runs its
     256 x 256 ping-pong tiles on more than FLAT2_KMAX channels (it wins there). 64-column tiles (bit 4) where 128-column ones
@@ -464,10 +470,10 @@ def _rows_flags(x: Act, N: int, K: Optional[int] = None) -> int:
     if call("insar_igemm_tile_cols_dt", M, N, x.code) == 256:
         # ... also against the 256 x 256 ping-pong tiles where K is short (256 -> 256 at 64^2 73 / 82 -> 65 / 65 us, 128 -> 256 at
         # 128^2 141 -> 133; at K = 512 the two are equal alone and the step reads 0.01 ms better: profiles/r04_flat2.txt, item 8)
-        return (8 | 32 | (4 if FLAT_PERSIST else 0)) if (two and (x.c_len if K is None else K) <= FLAT2_KMAX) else 0
+        return (8 | 32 | (4 if _flat2_persist(flip) else 0)) if (two and (x.c_len if K is None else K) <= FLAT2_KMAX) else 0
     narrow = (N % 128) != 0 or (M // 256) * (N // 128) < 256
     if two:
-        return 8 | 32 | (4 if FLAT_PERSIST else 0)
+        return 8 | 32 | (4 if _flat2_persist(flip) else 0)
     return 8 | (16 if narrow else 0)
 
 
@@ -658,7 +664,7 @@ class ConvBN:
         # the rest: per-tap implicit GEMM, or (bf16, where that kernel would not run its 256 x 256 tiles) the flat kernel's row tiles
         plain = not (self.small or self.c64)
         self.rows_fwd = _rows_flags(x, self.cout) if (plain and not self.flat_fwd) else 0
-        self.rows_bwd = _rows_flags(x, self.cin, self.cout) if (plain and not self.flat_bwd) else 0
+        self.rows_bwd = _rows_flags(x, self.cin, self.cout, flip=1) if (plain and not self.flat_bwd) else 0
         if self.small:
             self.stat_rows = call("insar_conv3x3_small_fwd_rows", x.ref, self.y.ref)
         elif self.rows_fwd:
