@@ -491,7 +491,10 @@ def _conv3x3_flat(x: Act, y: Act, w: torch.Tensor, flip: int, stats: Optional[to
                                                    (" row tiles" + (" dilated" if (geo >> 8) & 15 else "")) if geo else "", " +bstat" if bstat is not None else "")
         if flags & 32:
             tag = "conv3x3_flat2_kernel<%d, %s, %d>" % (128 if y.c_len % 128 == 0 else 64, "true" if bstat is not None else "false", (flags >> 3) & 1)
-        PROFILER.run(tag, flops, fn)
+        # algorithmic bytes of the launch: the input and the output once, the nine weight slabs once (+ the consumer's y for +bstat)
+        es = 2 if x.code == _lib.BF16 else 4
+        nbytes = float(x.B * x.H * x.W * (x.c_len + y.c_len * (2 if bstat is not None else 1)) * es + 9 * x.c_len * y.c_len * es)
+        PROFILER.run(tag, flops, fn, nbytes)
         return
     fn()
 
