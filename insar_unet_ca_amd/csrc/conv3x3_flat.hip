@@ -603,7 +603,7 @@ extern "C" int insar_conv3x3_flat_stat_rows(const InsarAct* x, int32_t N, int32_
   const int mt = (flip & 8) ? (int)(((long long)x->B * x->H * x->W) / FL_BM) : flat_mtiles(flat_pixels(*x));
   if (!(flip & 4) || ((flip & 8) && !(flip & 32))) return mt;      // (the two-work-group kernel's row tiles have a persistent form)
   const int bn = ((N % 128) == 0 && !(flip & 16)) ? 128 : 64;
-  const int cus = (flip & 32) ? insar_flat2_persistent_grid() : (insar_num_cus() & ~7);      // bit 5: two work-groups per CU
+  const int cus = (flip & 32) ? insar_flat2_persistent_grid(bn) : (insar_num_cus() & ~7);      // bit 5: two (three) work-groups per CU
   const long long grid = (long long)mt * (N / bn);
   return (cus >= 8 && grid > cus && N / bn == 1) ? cus : mt;
 }

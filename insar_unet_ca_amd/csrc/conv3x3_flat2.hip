@@ -6,7 +6,8 @@
 // BatchNorm sums — runs with the matrix pipes idle, and at the shallow levels K is short (9-18 tap steps of 64 channels), so
 // that serial part is 25-45 % of a launch (profiles/r04_stamps_flat.txt). Here a work-group is 4 waves (one per SIMD) on the
 // same 256-pixel x BN tile with HALF-WIDTH K slabs (32 channels = 64-byte LDS rows): ring 2 x 16 KB (A, one slot per dy
-// group) + 3 x 8 KB (B, one slot per tap) = 56 KB, epilogue tile 68 KB, 74 KB in all — two work-groups fit the 160 KB, each
+// group) + 3 x 8 KB (B, one slot per tap) = 56 KB, epilogue tile 68 KB, 74 KB in all — two work-groups fit the 160 KB (three
+// on 64-column tiles: 49 KB, 64 accumulator registers), each
 // wave has the 256-register budget of two waves per SIMD, and one group's prologue / epilogue runs under the other's K loop
 // (the hardware alternates the two waves of a SIMD by itself: the MFMA pipe is the one thing they cannot both have).
 // Second effect: the wave tile is 128 pixels x 64 channels (BN = 128; 64 x 64 for BN = 64): 8 + 4 fragment reads per 32
@@ -32,6 +33,11 @@ typedef __attribute__((ext_vector_type(4))) float f2_f32x4_t;
 #define F2_STEP (F2_BM - 2)
 #define F2_THREADS 256
 #define F2_ROWB 64
+// work-groups per CU (= waves per SIMD): 64-column tiles need 49 KB of LDS and 64 accumulator registers — three fit
+#ifndef F2_WGS64
+#define F2_WGS64 3
+#endif
+#define F2_WGS(bn) ((bn) == 64 ? F2_WGS64 : 2)
 
 template <int BN, int GEO = 0>
 struct Flat2Cfg {
@@ -48,7 +54,7 @@ struct Flat2Cfg {
   static constexpr int ROWINFO = F2_BM * 8;
   static constexpr int STATB = 4 * BN * 2 * 4;
   static constexpr int LDS_BYTES = MAIN + ROWINFO + STATB;
-  static_assert(2 * LDS_BYTES <= 160 * 1024, "two work-groups per CU");
+  static_assert(F2_WGS(BN) * LDS_BYTES <= 160 * 1024, "co-resident work-groups per CU");
 };
 
 #ifdef INSAR_STAMPS
@@ -84,7 +90,7 @@ __device__ __forceinline__ int f2_swz(int row) { return ((row >> 2) & 1) << 1; }
 // computed, the tile count is M / 256 — 1024 / 4096 tiles at B = 16 where the flat geometry's 254-pixel step gives
 // 1065 / 4194: exactly 2 / 8 tiles for each of the 512 persistent work-groups instead of 3 / 9 for the unlucky ones.
 template <int BN, bool BS, int GEO>
-__global__ __launch_bounds__(F2_THREADS, 2) void conv3x3_flat2_kernel(FlatArgs a) {
+__global__ __launch_bounds__(F2_THREADS, F2_WGS(BN)) void conv3x3_flat2_kernel(FlatArgs a) {
   using Cfg = Flat2Cfg<BN, GEO>;
   constexpr int CH = 8, NT = 4;
   constexpr int WGM = BN == 128 ? 2 : 4;                  // waves along the pixel dimension
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(F2_THREADS, 2) void conv3x3_flat2_kernel(FlatArgs a
 }
 
 // ---- host side -----------------------------------------------------------------------------------
-int insar_flat2_persistent_grid() { return 2 * (insar_num_cus() & ~7); }
+int insar_flat2_persistent_grid(int bn) { return F2_WGS(bn) * (insar_num_cus() & ~7); }
 
 template <int BN, bool BS, int GEO>
 static int launch_flat2(FlatArgs& a, hipStream_t s) {
@@ -427,7 +433,7 @@ static int launch_flat2(FlatArgs& a, hipStream_t s) {
   a.total_tiles = (int)grid;
   a.carry = 0;
   if (a.persist) {                                   // two work-groups per CU, each walking its tiles
-    const int slots = insar_flat2_persistent_grid();
+    const int slots = insar_flat2_persistent_grid(BN);
     if (slots >= 16 && grid > slots) { grid = slots; a.carry = a.num_ntiles == 1 ? 1 : 0; }
   }
   hipLaunchKernelGGL((conv3x3_flat2_kernel<BN, BS, GEO>), dim3((unsigned)grid), dim3(F2_THREADS), Cfg::LDS_BYTES, s, a);

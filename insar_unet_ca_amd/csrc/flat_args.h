@@ -23,5 +23,5 @@ struct FlatArgs {
 // bn = 128 / 64 columns per tile.
 int insar_flat2_launch(FlatArgs& a, int bn, bool bstat, bool rows, hipStream_t s);
 bool insar_flat2_rows_geometry(const InsarAct& x);
-// grid of a persistent flat2 launch (two work-groups per CU)
-int insar_flat2_persistent_grid();
+// grid of a persistent flat2 launch (two work-groups per CU; three on 64-column tiles)
+int insar_flat2_persistent_grid(int bn);
