@@ -17,16 +17,16 @@ echo "== bench"; timeout -k 10 400 python3 "$R/bench.py" > "$OUT/bench.json" 2> 
 cut -c1-330 "$OUT/bench.json"
 echo "== phase times"; timeout -k 10 100 python3 "$R/tools/phase_times.py" 2>/dev/null | tee "$OUT/phase_times.log"
 echo "== rocprof stats (default command: timed region on two streams + the two event passes)"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/p1" -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs > "$OUT/p1.log" 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/p1" -- python3 "$R/bench.py" --steps 10 --warmup 3 --settle 0 --no-cpu-baseline --no-other-configs > "$OUT/p1.log" 2>&1 || exit 1
 echo "== rocprof stats (timed region only, two streams)"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/p3" -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/p3.log" 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/p3" -- python3 "$R/bench.py" --steps 10 --warmup 3 --settle 0 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/p3.log" 2>&1 || exit 1
 echo "== rocprof stats (single stream)"
-INSAR_SIDE_STREAM=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/p2" -- python3 "$R/bench.py" --allow-switches --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/p2.log" 2>&1 || exit 1
+INSAR_SIDE_STREAM=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/p2" -- python3 "$R/bench.py" --allow-switches --steps 10 --warmup 3 --settle 0 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/p2.log" 2>&1 || exit 1
 echo "== PMC passes (launch configuration of the timed region: split-K factors for the side stream; the profiler serialises the kernels)"
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pF" -- python3 "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/pF.log" 2>&1 || exit 1
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pW" -- python3 "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/pW.log" 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pF" -- python3 "$R/bench.py" --steps 4 --warmup 1 --settle 0 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/pF.log" 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pW" -- python3 "$R/bench.py" --steps 4 --warmup 1 --settle 0 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/pW.log" 2>&1 || exit 1
 echo "== kernel trace (timeline of 4 steady-state steps)"
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/pT" -- python3 "$R/bench.py" --steps 4 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/pT.log" 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/pT" -- python3 "$R/bench.py" --steps 4 --warmup 3 --settle 0 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/pT.log" 2>&1 || exit 1
 cp $(ls "$OUT"/p1/*/*_kernel_stats.csv | head -n 1) "$OUT/bench_kernel_stats.csv"
 cp $(ls "$OUT"/p3/*/*_kernel_stats.csv | head -n 1) "$OUT/bench_kernel_stats_timed_region.csv"
 cp $(ls "$OUT"/p2/*/*_kernel_stats.csv | head -n 1) "$OUT/bench_kernel_stats_single_stream.csv"
@@ -39,7 +39,7 @@ rm -rf "$OUT/p1" "$OUT/p2" "$OUT/p3" "$OUT/pF" "$OUT/pW" "$OUT/pT" "$OUT/pmc_fet
 fi
 if [ "$PART" = "a" ]; then echo "part a done"; exit 0; fi
 echo "== SQ counters (one PMC pass, single stream: every kernel alone on the chip)"
-INSAR_SIDE_STREAM=0 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/pS" -- python3 "$R/bench.py" --allow-switches --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/pS.log" 2>&1 && python3 "$R/tools/sq_counters.py" $(ls "$OUT"/pS/*/*_counter_collection.csv | head -n 1) 1e8 | tee "$OUT/pmc_sq_counters.txt"
+INSAR_SIDE_STREAM=0 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/pS" -- python3 "$R/bench.py" --allow-switches --steps 3 --warmup 1 --settle 0 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/pS.log" 2>&1 && python3 "$R/tools/sq_counters.py" $(ls "$OUT"/pS/*/*_counter_collection.csv | head -n 1) 1e8 | tee "$OUT/pmc_sq_counters.txt"
 rm -rf "$OUT/pS"
 echo "== in-kernel stamps (diagnostic build of the library)"
 if [ -f "$R/insar_unet_ca_amd/libinsar_hip_stamps.so" ]; then

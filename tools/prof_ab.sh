@@ -4,8 +4,8 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$2; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/base" -- python3 "$R/bench.py" --allow-switches --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/base.log" 2>&1 || exit 1
-INSAR_HIP_LIB=$R/$1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/exp" -- python3 "$R/bench.py" --allow-switches --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/exp.log" 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/base" -- python3 "$R/bench.py" --allow-switches --steps 20 --warmup 5 --settle 0 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/base.log" 2>&1 || exit 1
+INSAR_HIP_LIB=$R/$1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/exp" -- python3 "$R/bench.py" --allow-switches --steps 20 --warmup 5 --settle 0 --no-cpu-baseline --no-kernel-timing --no-other-configs > "$OUT/exp.log" 2>&1 || exit 1
 for v in base exp; do cp "$(ls "$OUT"/$v/*/*kernel_stats.csv | head -1)" "$OUT/${v}_kernel_stats.csv"; rm -rf "$OUT/$v"; done
 python3 - "$OUT" <<'P'
 import csv, sys
