@@ -500,6 +500,7 @@ def main() -> int:
             print("error: --wgrad-fill must lie in [0.05, 1]", file=sys.stderr)
             return 2
         engine.WGRAD_FILL_T = min(1.0, engine.WGRAD_FILL_T * args.wgrad_fill / engine.WGRAD_FILL)
+        engine.WGRAD_FILL_SMALL = min(1.0, engine.WGRAD_FILL_SMALL * args.wgrad_fill / engine.WGRAD_FILL)
         engine.WGRAD_FILL = args.wgrad_fill
 
     if world > 1:
@@ -513,7 +514,7 @@ def main() -> int:
         return out
     if rank == 0 and isinstance(out, dict):
         out["switches"] = {k: v["value"] for k, v in sw.items()}
-        out["wgrad_fill"] = {"conv3x3": engine.WGRAD_FILL, "conv_transpose": engine.WGRAD_FILL_T, "deeplab": engine.WGRAD_FILL_DL}
+        out["wgrad_fill"] = {"conv3x3": engine.WGRAD_FILL, "conv3x3_small_tiles": engine.WGRAD_FILL_SMALL, "conv_transpose": engine.WGRAD_FILL_T, "deeplab": engine.WGRAD_FILL_DL}
         if world == 1 and not args.no_other_configs and args.model == "unet" and args.dtype == "bf16" and args.size == 256:
             out["other_configs"] = other_configs(args, dev, dist, iu, engine, make_batch)
         if world == 1 and not args.no_cpu_baseline and args.model == "unet":

@@ -360,6 +360,7 @@ OUTC_WGRAD_FUSE = os.environ.get("INSAR_OUTC_WGRAD_FUSE", "1") != "0"   # diagno
 WGRAD_FILL_T = float(os.environ.get("INSAR_WGRAD_FILL_T", "0.7"))   # the same for the transposed convs' per-tap weight gradient
 WGRAD_FILL_DL = float(os.environ.get("INSAR_WGRAD_FILL_DL", "0.5"))  # ... and for DeepLabV3-CA's per-tap weight gradients (1x1 / dilated / strided convs: most of its side stream; config 5 same-box 0.5 9.32, 0.6 9.42, 0.7 9.51, 0.85 9.60 ms/step)
 WGRAD_FILL_ALONE = float(os.environ.get("INSAR_WGRAD_FILL_ALONE", "1.0"))   # ... and when it has the GPU to itself
+WGRAD_FILL_SMALL = float(os.environ.get("INSAR_WGRAD_FILL_SMALL", os.environ.get("INSAR_WGRAD_FILL", "0.5")))   # ... for the 64- / 128-channel layers of the 256^2 / 128^2 levels (csrc/wgrad3.hip), which are HBM-heavy where the deep layers are MFMA-bound (swept 0.3 - 1.0: nothing beats the deep layers' value, profiles/r04_flat2.txt item 12)
 WGRAD_FILL = float(os.environ.get("INSAR_WGRAD_FILL", "0.5"))     # share of the work-group slots a side-stream weight gradient aims at. Re-swept whenever the main queue's kernels change: 0.5 in round 2, 0.6 with round 3's row tiles (profiles/r03_row_tiles.txt), 0.5 again with the two-work-group flat kernel (same box, 120-step runs: 0.4 6.85, 0.45 6.80, 0.5 6.74, 0.55 6.79, 0.6 6.79, 0.7 6.80 ms/step; profiles/r04_flat2.txt)
 WGRAD_ROWS = os.environ.get("INSAR_WGRAD_ROWS", "1") != "0"      # diagnostic: 0 = per-tap weight-gradient kernel everywhere
 WGRAD_K = os.environ.get("INSAR_WGRAD_K", "0") != "0"            # 1 = wgrad3k.hip (pixel slices per wave) for the 64 / 128-channel layers named by INSAR_WGRAD_K_TILES. Off: faster alone on two tile shapes, but in the step 6.90 vs 6.915 ms in three interleaved rounds (its KS slabs per work-group cost more fold traffic than the loop saves)
@@ -1024,7 +1025,7 @@ def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
         # main stream's kernels keep CUs, there are half as many slabs to fold, and the launch still ends before the
         # next one is due (same-box sweep of the fill factor: 1.0 8.09-8.14, 0.7 7.86, 0.5 7.81-7.86, 0.35 7.86, 0.25
         # 9.26 ms/step). Alone on the GPU (single-stream runs, the per-kernel event pass of bench.py) it fills the chip.
-        fill = _side_fill(ctx, WGRAD_FILL) if (ctx.side is not None and not (PROFILER is not None and PROFILER.alone)) else WGRAD_FILL_ALONE
+        fill = _side_fill(ctx, WGRAD_FILL if pairx else WGRAD_FILL_SMALL) if (ctx.side is not None and not (PROFILER is not None and PROFILER.alone)) else WGRAD_FILL_ALONE
         nsplit = _wgrad_nsplit(tiles, B * H * W // WG_BKP, 9 * cout * cin, tm, tn, ctx.esize, taps_per_wg=3, fill=fill)
         if WGRAD_GRID_CAP and fill < 1.0 and tm * tn >= 128 * 128:
             # deep layers (48 - 192 tiles): the cost model lands on 240 - 384 one-per-CU work-groups; beside the dgrad chain a
