@@ -228,6 +228,11 @@ int insar_wgrad_conv3(const InsarAct* x, const InsarAct* dy, float* part, int32_
  * insar_wgrad_conv3x_tile: (tile(Cin) << 16) | tile(Cout), or 0 where the layer keeps insar_wgrad_conv3. */
 int insar_wgrad_conv3x_tile(const InsarAct* x, int32_t Cout);
 int insar_wgrad_conv3x(const InsarAct* x, const InsarAct* dy, float* part, int32_t nsplit, void* stream);
+/* ... and from 128 x 128 tiles by 4-wave work-groups built to run TWO PER CU (csrc/wgrad3y.hip: the same 64 x 64 x three-tap wave
+ * tiles and LDS image, a two-slot LDS ring of 34 KB stages, one barrier per K step, the two work-groups of a CU not coupled at all):
+ * bf16 layers with both channel counts multiples of 128. insar_wgrad_conv3y_tile: (128 << 16) | 128, or 0. */
+int insar_wgrad_conv3y_tile(const InsarAct* x, int32_t Cout);
+int insar_wgrad_conv3y(const InsarAct* x, const InsarAct* dy, float* part, int32_t nsplit, void* stream);
 /* The same decomposition for the bf16 layers with 64 or 128 channels on BOTH sides (the 256^2 / 128^2 levels): the tile is
  * too small to give eight waves a 64 x 64 x three-tap tile each, so the waves of a work-group split the PIXELS of a K step
  * (KS = 8 / wave tiles slices of 32 pixels) and a work-group writes KS slabs: part[nsplit * KS][9][Cout][Cin], folded by

@@ -116,6 +116,8 @@ _SIGNATURES = {
     "insar_wgrad_conv3": [_AP, _AP, _P, _I, _P],
     "insar_wgrad_conv3x_tile": [_AP, _I],
     "insar_wgrad_conv3x": [_AP, _AP, _P, _I, _P],
+    "insar_wgrad_conv3y_tile": [_AP, _I],
+    "insar_wgrad_conv3y": [_AP, _AP, _P, _I, _P],
     "insar_wgrad_conv3k_tile": [_AP, _I],
     "insar_wgrad_conv3k_slices": [_AP, _I],
     "insar_wgrad_conv3k": [_AP, _AP, _P, _I, _P],
@@ -226,7 +228,7 @@ def load():
     return lib
 
 
-_COUNT_ONLY = {"insar_tune_get", "insar_igemm_num_mtiles", "insar_igemm_tile_rows", "insar_igemm_tile_cols", "insar_igemm_tile_cols_dt", "insar_wgrad_tile", "insar_wgrad_tile_pair", "insar_wgrad_conv3_tile", "insar_wgrad_conv3x_tile", "insar_wgrad_conv3k_tile", "insar_wgrad_conv3k_slices", "insar_conv3x3_flat_ok", "insar_conv3x3_flat_rows_ok", "insar_conv3x3_flat2_rows_ok", "insar_conv3x3_flat_rows_dil_ok", "insar_conv3x3_flat_num_mtiles", "insar_conv3x3_flat_stat_rows", "insar_conv3x3_c64_ok", "insar_conv3x3_c64_rows", "insar_conv3x3_c64_geometry", "insar_conv3x3_small_wgrad_blocks", "insar_conv3x3_small_wgrad_fused_ok", "insar_conv3x3_small_fwd_rows", "insar_conv1x1_out_bwd_blocks",
+_COUNT_ONLY = {"insar_tune_get", "insar_igemm_num_mtiles", "insar_igemm_tile_rows", "insar_igemm_tile_cols", "insar_igemm_tile_cols_dt", "insar_wgrad_tile", "insar_wgrad_tile_pair", "insar_wgrad_conv3_tile", "insar_wgrad_conv3x_tile", "insar_wgrad_conv3y_tile", "insar_wgrad_conv3k_tile", "insar_wgrad_conv3k_slices", "insar_conv3x3_flat_ok", "insar_conv3x3_flat_rows_ok", "insar_conv3x3_flat2_rows_ok", "insar_conv3x3_flat_rows_dil_ok", "insar_conv3x3_flat_num_mtiles", "insar_conv3x3_flat_stat_rows", "insar_conv3x3_c64_ok", "insar_conv3x3_c64_rows", "insar_conv3x3_c64_geometry", "insar_conv3x3_small_wgrad_blocks", "insar_conv3x3_small_wgrad_fused_ok", "insar_conv3x3_small_fwd_rows", "insar_conv1x1_out_bwd_blocks",
                "insar_ce_blocks", "insar_conv7x7s2_fwd_rows", "insar_conv7x7s2_wgrad_blocks"}
 
 

@@ -369,6 +369,7 @@ WGRAD_K = os.environ.get("INSAR_WGRAD_K", "0") != "0"            # 1 = wgrad3k.h
 # 128-tile kernel except 64 x 64 (+0.07 ms): the shallow levels are not bound by the K loop's structure
 WGRAD_K_TILES = set(os.environ.get("INSAR_WGRAD_K_TILES", "128x64,128x128").split(","))
 WGRAD_X = os.environ.get("INSAR_WGRAD_X", "1") != "0"            # diagnostic: 0 = the 128 x 128 row-of-taps kernel (wgrad3.hip) also where the 256 x 128 six-phase kernel (wgrad3x.hip) applies; slabs bit for bit equal at equal nsplit
+WGRAD_Y = int(os.environ.get("INSAR_WGRAD_Y", "0"))            # ... on 128 x 128 tiles by 4-wave work-groups, two per CU (csrc/wgrad3y.hip), instead of wgrad3x wherever both channel counts are multiples of 128: 1 = on
 FLAT_PP = int(os.environ.get("INSAR_FLAT_PP", "1"))               # flat 3x3 kernel: ping-pong tap steps (0 = plain loop; bitwise equal)
 FLAT_PERSIST = int(os.environ.get("INSAR_FLAT_PERSIST", "2"))     # flat 3x3 kernel: one work-group per CU walking its tiles (bitwise equal): 1 = forward launches, 2 = all (default since round 3: with the BatchNorm-backward sums carried over a work-group's tiles the input-gradient launches gain too, same-box 7.55 -> 7.49 ms/step), 0 = off
 IGEMM_PP = int(os.environ.get("INSAR_IGEMM_PP", "1"))            # 256 x 256 tiles: ping-pong K loop (0 = the plain two-slab loop; bitwise equal)
@@ -993,6 +994,7 @@ def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
     cin, cout = x.c_len, dy.c_len
     pair = call("insar_wgrad_conv3_tile", x.ref, cout) if WGRAD_ROWS else 0
     pairx = call("insar_wgrad_conv3x_tile", x.ref, cout) if (WGRAD_ROWS and WGRAD_X) else 0
+    pairy = call("insar_wgrad_conv3y_tile", x.ref, cout) if (WGRAD_ROWS and WGRAD_Y and pairx) else 0
     pairk = call("insar_wgrad_conv3k_tile", x.ref, cout) if (WGRAD_ROWS and WGRAD_K and not pairx) else 0
     if pairk and "%dx%d" % (pairk >> 16, pairk & 0xffff) not in WGRAD_K_TILES:
         pairk = 0
@@ -1013,6 +1015,21 @@ def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
         else:
             call("insar_wgrad_conv3k", x.ref, dy.ref, ptr(part), nsplit, _lib.stream_ptr())
         ctx.wgrad_finish(part, grad, nsplit * ks, 9, cout, cin, 0)
+        return
+    if pairy:
+        # 128 x 128 tiles, two 4-wave work-groups per CU: the launch aims at twice the work-group count of the one-per-CU kernels
+        tiles = 3 * (cin // 128) * (cout // 128)
+        fill = _side_fill(ctx, WGRAD_FILL) if (ctx.side is not None and not (PROFILER is not None and PROFILER.alone)) else WGRAD_FILL_ALONE
+        ksteps = B * H * W // WG_BKP
+        nsplit = max(1, min(int(512 * fill) // tiles, ksteps // 4))
+        part = ctx.wgrad_part(nsplit * 9 * cout * cin)
+        if PROFILER is not None:
+            nbytes = ctx.esize * B * H * W * (cin + cout) + 4.0 * nsplit * 9 * cout * cin
+            PROFILER.run("wgrad3y_kernel<128, 128>", 2.0 * B * H * W * cin * cout * 9,
+                         lambda: call("insar_wgrad_conv3y", x.ref, dy.ref, ptr(part), nsplit, _lib.stream_ptr()), nbytes)
+        else:
+            call("insar_wgrad_conv3y", x.ref, dy.ref, ptr(part), nsplit, _lib.stream_ptr())
+        ctx.wgrad_finish(part, grad, nsplit, 9, cout, cin, 0)
         return
     if pair or pairx:
         # three taps of a kernel row per work-group (csrc/wgrad3.hip): a third of the operand staging; where one side has

@@ -151,7 +151,7 @@ class PlanTape:
         bn = tuple((m.momentum, m.eps) for m in self.bn_modules)
         # module-level switches the launch code reads at call time (tests flip them with monkeypatch): part of the key too
         flags = (engine.BSTAT_FUSE, engine.BSTAT_C64, engine.COEF_SIMPLE, engine.COEF_FUSE, engine.SPLIT_COEF, engine.POOL_FUSE,
-                 engine.OUTC_FUSE, engine.OUTC_WGRAD_FUSE, engine.PREP_SIDE, engine.SMALL_WGRAD_MAIN, engine.SMALL_WGRAD_FUSE, engine.WGRAD_LATE, engine.WGRAD_ROWS, engine.WGRAD_X, engine.WGRAD_K, engine.FLAT_PP, engine.FLAT2, engine.FLAT2_KMAX, engine.FLAT2_PERSIST,
+                 engine.OUTC_FUSE, engine.OUTC_WGRAD_FUSE, engine.PREP_SIDE, engine.SMALL_WGRAD_MAIN, engine.SMALL_WGRAD_FUSE, engine.WGRAD_LATE, engine.WGRAD_ROWS, engine.WGRAD_X, engine.WGRAD_Y, engine.WGRAD_K, engine.FLAT_PP, engine.FLAT2, engine.FLAT2_KMAX, engine.FLAT2_PERSIST,
                  engine.FLAT_PERSIST, engine.FLAT_ROWS, engine.IGEMM_PP, engine.WGRAD_FILL, engine.WGRAD_FILL_SMALL, engine.WGRAD_FILL_T, engine.WGRAD_FILL_DL, engine.WGRAD_GRID_CAP,
                  getattr(sys.modules.get(__package__ + ".deeplab"), "GATE_FUSE", None), getattr(sys.modules.get(__package__ + ".deeplab"), "GATE_STATS", None))
         return (which, self.sink.active if which == "b" else 0, hash(bn), hash(flags))

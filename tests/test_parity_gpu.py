@@ -231,6 +231,12 @@ def test_wgrad_conv3x_against_float64_and_the_128_tile_kernel(dev, cin, cout, sh
         call("insar_wgrad_conv3x", xa.ref, ga.ref, ptr(pb), nsplit, _lib.stream_ptr())
         torch.cuda.synchronize()
         assert torch.equal(pa, pb), (nsplit, float((pa - pb).abs().max()))
+        # csrc/wgrad3y.hip: 128 x 128 tiles, 4-wave work-groups (two per CU), two-slot ring, one barrier per K step
+        assert call("insar_wgrad_conv3y_tile", xa.ref, cout) == (128 << 16) | 128
+        pc = torch.full((nsplit * slab,), float("nan"), device=dev)
+        call("insar_wgrad_conv3y", xa.ref, ga.ref, ptr(pc), nsplit, _lib.stream_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(pa, pc), ("wgrad3y", nsplit, float((pa - pc).abs().max()))
         gwt = torch.zeros(cout, cin, 3, 3, device=dev)
         ctx.wgrad_finish(pb, gwt, nsplit, 9, cout, cin, 0)
         assert max_rel(gwt, wv.grad) <= KERNEL_TOL * 5, nsplit
@@ -245,11 +251,13 @@ def test_wgrad_conv3x_against_float64_and_the_128_tile_kernel(dev, cin, cout, sh
     (1024, 1024, (16, 1024, 16, 16), 2), # down4.3: four image rows per K step, 32 steps per work-group
     (256, 128, (4, 256, 32, 64), 9),     # ragged split: 128 K steps over 9 splits
 ])
-def test_wgrad_conv3x_race_screen(dev, cin, cout, shape, nsplit):
+@pytest.mark.parametrize("entry", ["insar_wgrad_conv3x", "insar_wgrad_conv3y"])
+def test_wgrad_conv3x_race_screen(dev, cin, cout, shape, nsplit, entry):
     """The six-phase K loop is a NEW synchronisation structure (three-slot ring, one counted vmcnt per step, two wave groups a
     barrier apart): a read that runs ahead of the wait that retires its slot passes every reference check whenever the DMA
     happens to land first. Screen: the same launch 150 times, half of them beside a stream that keeps the memory system busy
-    (the situation in which round 1's WAR race showed), every slab bit for bit the first one."""
+    (the situation in which round 1's WAR race showed), every slab bit for bit the first one. Also for csrc/wgrad3y.hip (two-slot
+    ring, one barrier per step, a second work-group of the same launch on the CU)."""
     from insar_unet_ca_amd import engine, _lib
     from insar_unet_ca_amd._lib import call, ptr
     dtype = torch.bfloat16
@@ -262,7 +270,7 @@ def test_wgrad_conv3x_race_screen(dev, cin, cout, shape, nsplit):
     assert call("insar_wgrad_conv3x_tile", xa.ref, cout)
     n = nsplit * 9 * cout * cin
     ref = torch.empty(n, device=dev)
-    call("insar_wgrad_conv3x", xa.ref, ga.ref, ptr(ref), nsplit, _lib.stream_ptr())
+    call(entry, xa.ref, ga.ref, ptr(ref), nsplit, _lib.stream_ptr())
     torch.cuda.synchronize()
     side = torch.cuda.Stream(device=dev)
     noise = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
@@ -273,7 +281,7 @@ def test_wgrad_conv3x_race_screen(dev, cin, cout, shape, nsplit):
             with torch.cuda.stream(side):
                 noise.copy_(noise.flip(0))                        # 128 MB of traffic beside the launch
         out.fill_(float("nan"))
-        call("insar_wgrad_conv3x", xa.ref, ga.ref, ptr(out), nsplit, _lib.stream_ptr())
+        call(entry, xa.ref, ga.ref, ptr(out), nsplit, _lib.stream_ptr())
         torch.cuda.synchronize()
         bad += int(not torch.equal(out, ref))
     assert bad == 0, f"{bad} of 150 launches differ from the first"

@@ -184,6 +184,26 @@ def main():
             for v in vals[1:]:
                 d = (outs[v] - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
                 res.append(f"max|{kname}={v} - {kname}={vals[0]}|/max = {d:.2e}" + (" (bitwise)" if torch.equal(outs[v], ref) else ""))
+        if "y3" in what:       # wgrad3y.hip (128 x 128 tiles, two 4-wave work-groups per CU) against wgrad3x.hip (256 x 128, one 8-wave group per CU)
+            pairx = call("insar_wgrad_conv3x_tile", x.ref, cout)
+            if pairx and call("insar_wgrad_conv3y_tile", x.ref, cout):
+                tmx, tnx = pairx >> 16, pairx & 0xffff
+                tiles_x = 3 * (cin // tmx) * (cout // tnx)
+                tiles_y = 3 * (cin // 128) * (cout // 128)
+                ks = M // 64
+                part_ = ctx.wgrad_part(max(1, 512 // tiles_y + 1, 256 // tiles_x + 1) * 9 * cout * cin)
+                def fx(n): return lambda: call("insar_wgrad_conv3x", x.ref, g.ref, _lib.ptr(part_), n, _lib.stream_ptr())
+                def fy(n): return lambda: call("insar_wgrad_conv3y", x.ref, g.ref, _lib.ptr(part_), n, _lib.stream_ptr())
+                part_.zero_(); fx(1)(); torch.cuda.synchronize(); ref = part_[:9 * cout * cin].clone()
+                part_.zero_(); fy(1)(); torch.cuda.synchronize(); got = part_[:9 * cout * cin].clone()
+                res.append(f"bitwise@nsplit=1: {torch.equal(ref, got)}")
+                for cus in (256, 128):          # the share of the chip the launch aims at: whole / half (as beside the dgrad chain)
+                    nx = max(1, min(cus // tiles_x, ks // 4)); ny = max(1, min(2 * cus // tiles_y, ks // 4))
+                    rx, ry = [], []
+                    for r in range(4):
+                        rx.append(run(fx(nx))); ry.append(run(fy(ny)))
+                    res.append(f"\n   {cus} CUs: wgrad3x {tmx}x{tnx} nsplit {nx:3d} grid {nx * tiles_x:4d}: {min(rx):6.1f} us ({flops/min(rx)/1e6:5.0f} TF) | "
+                               f"wgrad3y 128x128 nsplit {ny:3d} grid {ny * tiles_y:4d}: {min(ry):6.1f} us ({flops/min(ry)/1e6:5.0f} TF)")
         if "x3" in what:       # the 256 x 128 six-phase weight-gradient kernel (wgrad3x.hip) against the 128 x 128 row-of-taps one
             pairx = call("insar_wgrad_conv3x_tile", x.ref, cout)
             pair3 = call("insar_wgrad_conv3_tile", x.ref, cout)
