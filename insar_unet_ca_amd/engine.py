@@ -369,7 +369,7 @@ WGRAD_K = os.environ.get("INSAR_WGRAD_K", "0") != "0"            # 1 = wgrad3k.h
 # 128-tile kernel except 64 x 64 (+0.07 ms): the shallow levels are not bound by the K loop's structure
 WGRAD_K_TILES = set(os.environ.get("INSAR_WGRAD_K_TILES", "128x64,128x128").split(","))
 WGRAD_X = os.environ.get("INSAR_WGRAD_X", "1") != "0"            # diagnostic: 0 = the 128 x 128 row-of-taps kernel (wgrad3.hip) also where the 256 x 128 six-phase kernel (wgrad3x.hip) applies; slabs bit for bit equal at equal nsplit
-WGRAD_Y = int(os.environ.get("INSAR_WGRAD_Y", "0"))            # ... on 128 x 128 tiles by 4-wave work-groups, two per CU (csrc/wgrad3y.hip), instead of wgrad3x wherever both channel counts are multiples of 128: 1 = on
+WGRAD_Y = int(os.environ.get("INSAR_WGRAD_Y", "0"))            # ... on 128 x 128 tiles by 4-wave work-groups, two per CU (csrc/wgrad3y.hip), bit 0: instead of wgrad3x wherever both channel counts are multiples of 128, bit 1: instead of wgrad3<128,128> (the 128 -> 128 layers). Measured slower both ways (profiles/r04_wgrad3y.txt)
 FLAT_PP = int(os.environ.get("INSAR_FLAT_PP", "1"))               # flat 3x3 kernel: ping-pong tap steps (0 = plain loop; bitwise equal)
 FLAT_PERSIST = int(os.environ.get("INSAR_FLAT_PERSIST", "2"))     # flat 3x3 kernel: one work-group per CU walking its tiles (bitwise equal): 1 = forward launches, 2 = all (default since round 3: with the BatchNorm-backward sums carried over a work-group's tiles the input-gradient launches gain too, same-box 7.55 -> 7.49 ms/step), 0 = off
 IGEMM_PP = int(os.environ.get("INSAR_IGEMM_PP", "1"))            # 256 x 256 tiles: ping-pong K loop (0 = the plain two-slab loop; bitwise equal)
@@ -994,7 +994,7 @@ def _wgrad_conv3(ctx: Ctx, x: Act, dy: Act, grad: torch.Tensor) -> None:
     cin, cout = x.c_len, dy.c_len
     pair = call("insar_wgrad_conv3_tile", x.ref, cout) if WGRAD_ROWS else 0
     pairx = call("insar_wgrad_conv3x_tile", x.ref, cout) if (WGRAD_ROWS and WGRAD_X) else 0
-    pairy = call("insar_wgrad_conv3y_tile", x.ref, cout) if (WGRAD_ROWS and WGRAD_Y and pairx) else 0
+    pairy = call("insar_wgrad_conv3y_tile", x.ref, cout) if (WGRAD_ROWS and ((WGRAD_Y & 1 and pairx) or (WGRAD_Y & 2 and not pairx))) else 0
     pairk = call("insar_wgrad_conv3k_tile", x.ref, cout) if (WGRAD_ROWS and WGRAD_K and not pairx) else 0
     if pairk and "%dx%d" % (pairk >> 16, pairk & 0xffff) not in WGRAD_K_TILES:
         pairk = 0

@@ -186,6 +186,23 @@ def main():
                 res.append(f"max|{kname}={v} - {kname}={vals[0]}|/max = {d:.2e}" + (" (bitwise)" if torch.equal(outs[v], ref) else ""))
         if "y3" in what:       # wgrad3y.hip (128 x 128 tiles, two 4-wave work-groups per CU) against wgrad3x.hip (256 x 128, one 8-wave group per CU)
             pairx = call("insar_wgrad_conv3x_tile", x.ref, cout)
+            if not pairx and call("insar_wgrad_conv3y_tile", x.ref, cout) and call("insar_wgrad_conv3_tile", x.ref, cout):
+                # 128 x 128 layers: against the 8-wave 128-tile kernel (wgrad3.hip)
+                tiles = 3 * (cin // 128) * (cout // 128)
+                ks = M // 64
+                part_ = ctx.wgrad_part((512 // tiles + 1) * 9 * cout * cin)
+                def f3(n): return lambda: call("insar_wgrad_conv3", x.ref, g.ref, _lib.ptr(part_), n, _lib.stream_ptr())
+                def fy(n): return lambda: call("insar_wgrad_conv3y", x.ref, g.ref, _lib.ptr(part_), n, _lib.stream_ptr())
+                part_.zero_(); f3(2)(); torch.cuda.synchronize(); ref = part_[:2 * 9 * cout * cin].clone()
+                part_.zero_(); fy(2)(); torch.cuda.synchronize(); got = part_[:2 * 9 * cout * cin].clone()
+                res.append(f"bitwise@nsplit=2: {torch.equal(ref, got)}")
+                for cus in (256, 128):
+                    n3 = max(1, min(cus // tiles, ks // 4)); ny = max(1, min(2 * cus // tiles, ks // 4))
+                    r3, ry = [], []
+                    for r in range(4):
+                        r3.append(run(f3(n3))); ry.append(run(fy(ny)))
+                    res.append(f"\n   {cus} CUs: wgrad3 128x128 nsplit {n3:3d} grid {n3 * tiles:4d}: {min(r3):6.1f} us ({flops/min(r3)/1e6:5.0f} TF) | "
+                               f"wgrad3y 128x128 nsplit {ny:3d} grid {ny * tiles:4d}: {min(ry):6.1f} us ({flops/min(ry)/1e6:5.0f} TF)")
             if pairx and call("insar_wgrad_conv3y_tile", x.ref, cout):
                 tmx, tnx = pairx >> 16, pairx & 0xffff
                 tiles_x = 3 * (cin // tmx) * (cout // tnx)
