@@ -23,6 +23,7 @@ static const char* const g_knob_names[KNOB_COUNT] = {
     "igemm_wide_min",  // ... 256 x 128 tiles (instead of 256 x 64) where they give at least this many work-groups (0 = default 256)
     "wgrad_tile_max",  // per-tap weight gradient (insar_wgrad), bf16: largest tile edge (0 = default 256; 128 = no 256 x 256 tiles)
     "wgrad3x_var",     // experiment builds only (-DINSAR_EXP_WX): timing ablations of wgrad3x.hip's K loop (wrong results); ignored by the product library
+    "c64_grid_bwd",    // 64 -> 64 kernel, input-gradient launches (flip = 1): persistent work-groups (0 = one per CU)
 };
 static std::atomic<int> g_knobs[KNOB_COUNT] = {};     // defaults: 0
 int insar_knob(int id) { return g_knobs[id].load(std::memory_order_relaxed); }

@@ -24,7 +24,7 @@ void insar_set_error(const char* fmt, ...);
   } while (0)
 
 // ---- kernel-variant knobs (insar_tune_set / insar_tune_get, api.hip) ---------------------------
-enum InsarKnob { KNOB_WGRAD3_M32 = 0, KNOB_IGEMM_XWIDE_MIN, KNOB_IGEMM_WIDE_MIN, KNOB_WGRAD_TILE_MAX, KNOB_WGRAD3X_VAR, KNOB_COUNT };
+enum InsarKnob { KNOB_WGRAD3_M32 = 0, KNOB_IGEMM_XWIDE_MIN, KNOB_IGEMM_WIDE_MIN, KNOB_WGRAD_TILE_MAX, KNOB_WGRAD3X_VAR, KNOB_C64_GRID_BWD, KNOB_COUNT };
 int insar_knob(int id);
 
 static inline bool insar_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

@@ -406,8 +406,9 @@ extern "C" int insar_conv3x3_c64_geometry(const InsarAct* x, int32_t* out) {
 extern "C" int insar_conv3x3_c64_rows(const InsarAct* x) {
   C64Args a;
   if (!x || !c64_geometry(*x, a)) return 0;
-  const int cus = c64_num_cus();
-  return a.ntiles < cus ? a.ntiles : cus;
+  const int cus = c64_num_cus(), kb = insar_knob(KNOB_C64_GRID_BWD);
+  const int g = kb > cus ? kb : cus;                  // rows for either direction (rows a launch does not write stay zero)
+  return a.ntiles < g ? a.ntiles : g;
 }
 
 // y = conv3x3(x, w), 64 -> 64 channels, same (B, H, W) grid. w: [9][64][64] bf16 in (dy, dx) raster order;
@@ -441,7 +442,8 @@ static int c64_impl(const InsarAct* x, const InsarAct* y, const void* w, int32_t
                         : insar_set_lds_once(attr_mask, (const void*)conv3x3_c64_kernel<2>, C6_MAX_LDS);
     if (e != hipSuccess) INSAR_FAIL(-(int)e, "insar_conv3x3_c64: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
-  const int cus = c64_num_cus();
+  const int kb = insar_knob(KNOB_C64_GRID_BWD);
+  const int cus = (a.flip && kb > 0) ? kb : c64_num_cus();
   const int grid = a.ntiles < cus ? a.ntiles : cus;
   if (a.by) hipLaunchKernelGGL((conv3x3_c64_kernel<2, true>), dim3(grid), dim3(C6_THREADS), lds, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((conv3x3_c64_kernel<2>), dim3(grid), dim3(C6_THREADS), lds, (hipStream_t)stream, a);
